@@ -1,0 +1,238 @@
+"""ctypes binding of libkws_hip.so (C ABI: include/kws.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (``make -C honk2_amd/csrc``).  There is NO
+CPU fallback: if the library is missing, cannot be loaded, or no HIP device is present, every compute entry
+point raises ``RuntimeError``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkws_hip.so")
+
+KWS_MODEL_NONE, KWS_MODEL_RESNET, KWS_MODEL_CNN = 0, 1, 2
+KWS_DTYPE_F32 = 0
+
+# every symbol include/kws.h declares (tests check the library exports exactly these)
+EXPORTS = (
+    "kws_create", "kws_destroy", "kws_load_weights", "kws_workspace_bytes", "kws_set_workspace", "kws_num_frames",
+    "kws_mfcc", "kws_forward", "kws_forward_wav", "kws_eval_batch", "kws_plan_name", "kws_profile_enable",
+    "kws_profile_read", "kws_last_error", "kws_abi_version",
+)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("out_channels", C.c_int32), ("kernel_h", C.c_int32), ("kernel_w", C.c_int32),
+                ("stride_h", C.c_int32), ("stride_w", C.c_int32)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("family", C.c_int32), ("dtype", C.c_int32), ("n_labels", C.c_int32),
+        ("time", C.c_int32), ("freq", C.c_int32),
+        ("n_layers", C.c_int32), ("n_feature_maps", C.c_int32), ("use_dilation", C.c_int32),
+        ("pool_h", C.c_int32), ("pool_w", C.c_int32),
+        ("n_conv", C.c_int32), ("conv", ConvDesc * 2), ("pool_kh", C.c_int32 * 2), ("pool_kw", C.c_int32 * 2),
+        ("lin0_out", C.c_int32), ("dnn0_out", C.c_int32), ("dnn1_out", C.c_int32),
+        ("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("hop_length", C.c_int32), ("n_mels", C.c_int32),
+        ("f_min", C.c_float), ("f_max", C.c_float),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libkws_hip.so once; raises RuntimeError (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"honk2_amd: HIP extension {LIB_PATH} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C honk2_amd/csrc`). "
+            "There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError(f"honk2_amd: cannot load {LIB_PATH}: {e}") from e
+    vp, ci, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.kws_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
+    lib.kws_create.restype = ci
+    lib.kws_destroy.argtypes = [vp]
+    lib.kws_destroy.restype = None
+    lib.kws_load_weights.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.kws_load_weights.restype = ci
+    lib.kws_workspace_bytes.argtypes = [vp, ci, ci]
+    lib.kws_workspace_bytes.restype = sz
+    lib.kws_set_workspace.argtypes = [vp, vp, sz]
+    lib.kws_set_workspace.restype = ci
+    lib.kws_num_frames.argtypes = [vp, ci]
+    lib.kws_num_frames.restype = ci
+    lib.kws_mfcc.argtypes = [vp, vp, ci, ci, vp, vp]
+    lib.kws_mfcc.restype = ci
+    lib.kws_forward.argtypes = [vp, vp, ci, ci, vp, vp]
+    lib.kws_forward.restype = ci
+    lib.kws_forward_wav.argtypes = [vp, vp, ci, ci, vp, vp]
+    lib.kws_forward_wav.restype = ci
+    lib.kws_eval_batch.argtypes = [vp, vp, vp, ci, vp, vp, vp]
+    lib.kws_eval_batch.restype = ci
+    lib.kws_plan_name.argtypes = [vp]
+    lib.kws_plan_name.restype = C.c_char_p
+    lib.kws_profile_enable.argtypes = [vp, ci]
+    lib.kws_profile_enable.restype = ci
+    lib.kws_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]
+    lib.kws_profile_read.restype = ci
+    lib.kws_last_error.argtypes = []
+    lib.kws_last_error.restype = C.c_char_p
+    lib.kws_abi_version.argtypes = []
+    lib.kws_abi_version.restype = ci
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().kws_last_error().decode(errors="replace")
+        raise RuntimeError(f"honk2_amd: {what} failed ({rc}): {msg}")
+
+
+FRONTEND_DEFAULTS = dict(sample_rate=16000, n_fft=480, hop_length=160, n_mels=40, f_min=20.0, f_max=4000.0)
+
+
+def make_desc(family, n_labels=0, frontend=None, **kw):
+    d = ModelDesc()
+    d.struct_size = C.sizeof(ModelDesc)
+    d.family = family
+    d.dtype = KWS_DTYPE_F32
+    d.n_labels = n_labels
+    fe = dict(FRONTEND_DEFAULTS)
+    fe.update(frontend or {})
+    for k, v in fe.items():
+        setattr(d, k, v)
+    d.time = kw.pop("time", 101)
+    d.freq = kw.pop("freq", fe["n_mels"])
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+class Engine:
+    """Owns one kws_handle plus its torch-allocated workspace.  Device memory for I/O and scratch comes from
+    PyTorch (plumbing); all arithmetic happens inside libkws_hip.so."""
+
+    def __init__(self, desc):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("honk2_amd: no ROCm device visible to PyTorch; the HIP path is mandatory (no CPU fallback)")
+        self.lib = load()
+        self.desc = desc
+        self.handle = C.c_void_p()
+        check(self.lib.kws_create(C.byref(desc), C.byref(self.handle)), "kws_create")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._ws = None
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.kws_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters
+    def load_tensor(self, name, tensor):
+        import torch
+        t = tensor.detach()
+        if t.dtype == torch.int64:     # num_batches_tracked
+            return
+        host = t.to(device="cpu", dtype=torch.float32).contiguous()
+        check(self.lib.kws_load_weights(self.handle, name.encode(), C.c_void_p(host.data_ptr()),
+                                        host.numel() * 4), f"kws_load_weights({name})")
+
+    # ---- workspace
+    def _ensure_ws(self, batch, frames):
+        import torch
+        need = int(self.lib.kws_workspace_bytes(self.handle, batch, frames))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+            check(self.lib.kws_set_workspace(self.handle, C.c_void_p(self._ws.data_ptr()), self._ws.numel()),
+                  "kws_set_workspace")
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _check_in(self, t, ndim, what):
+        import torch
+        if not (isinstance(t, torch.Tensor) and t.is_cuda):
+            raise RuntimeError(f"honk2_amd: {what} must be a CUDA(ROCm) tensor; there is no CPU path")
+        if t.dim() != ndim:
+            raise ValueError(f"honk2_amd: {what} must have {ndim} dimensions, got {tuple(t.shape)}")
+        return t.to(dtype=torch.float32).contiguous()
+
+    # ---- compute
+    def num_frames(self, n_samples):
+        return int(self.lib.kws_num_frames(self.handle, int(n_samples)))
+
+    def mfcc(self, wav):
+        import torch
+        wav = self._check_in(wav, 2, "wav")
+        b, n = wav.shape
+        t = self.num_frames(n)
+        out = torch.empty((b, t, self.desc.n_mels), dtype=torch.float32, device=wav.device)
+        if b == 0:
+            return out
+        check(self.lib.kws_mfcc(self.handle, C.c_void_p(wav.data_ptr()), b, n, C.c_void_p(out.data_ptr()),
+                                self._stream()), "kws_mfcc")
+        return out
+
+    def forward(self, feat):
+        import torch
+        feat = self._check_in(feat, 3, "features")
+        b, t, f = feat.shape
+        if f != self.desc.freq:
+            raise ValueError(f"honk2_amd: expected {self.desc.freq} frequency bins, got {f}")
+        if b:
+            self._ensure_ws(b, t)
+        out = torch.empty((b, self.desc.n_labels), dtype=torch.float32, device=feat.device)
+        if b == 0:
+            return out
+        check(self.lib.kws_forward(self.handle, C.c_void_p(feat.data_ptr()), b, t, C.c_void_p(out.data_ptr()),
+                                   self._stream()), "kws_forward")
+        return out
+
+    def forward_wav(self, wav, out=None):
+        import torch
+        wav = self._check_in(wav, 2, "wav")
+        b, n = wav.shape
+        if b:
+            self._ensure_ws(b, self.num_frames(n))
+        if out is None:
+            out = torch.empty((b, self.desc.n_labels), dtype=torch.float32, device=wav.device)
+        if b == 0:
+            return out
+        check(self.lib.kws_forward_wav(self.handle, C.c_void_p(wav.data_ptr()), b, n, C.c_void_p(out.data_ptr()),
+                                       self._stream()), "kws_forward_wav")
+        return out
+
+    def eval_batch(self, logits, target, stats, loss_sum):
+        check(self.lib.kws_eval_batch(self.handle, C.c_void_p(logits.data_ptr()), C.c_void_p(target.data_ptr()),
+                                      logits.shape[0], C.c_void_p(stats.data_ptr()), C.c_void_p(loss_sum.data_ptr()),
+                                      self._stream()), "kws_eval_batch")
+
+    def plan_name(self):
+        return self.lib.kws_plan_name(self.handle).decode()
+
+    def profile_enable(self, on=True):
+        check(self.lib.kws_profile_enable(self.handle, int(bool(on))), "kws_profile_enable")
+
+    def profile_read(self):
+        m, f, n = C.c_double(), C.c_double(), C.c_int()
+        check(self.lib.kws_profile_read(self.handle, C.byref(m), C.byref(f), C.byref(n)), "kws_profile_read")
+        return m.value, f.value, n.value

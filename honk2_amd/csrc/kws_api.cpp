@@ -1,0 +1,677 @@
+// C ABI of libkws_hip.so (declared in include/kws.h): handle, execution plans, weight packing, dispatch.
+// No torch types, no exceptions across the boundary, no allocation or synchronisation in the compute calls.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "kws_internal.h"
+
+using namespace kws;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int fail_hip(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return KWS_EHIP;
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return fail_hip(_e, #expr); \
+    } while (0)
+
+struct DevMem {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    int upload(const void* src, size_t n) {
+        if (bytes < n) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+            bytes = 0;
+            HIP_TRY(hipMalloc(&p, n));
+            bytes = n;
+        }
+        HIP_TRY(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+        return KWS_OK;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum Plan { PLAN_FRONTEND_ONLY, PLAN_RESNET, PLAN_CNN };
+
+struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the layer-wise plans
+    ConvGeom g{};           // B/H/W/Ho/Wo filled per call for ResNet, at create for CNN
+    DevMem apk, bias;
+    bool has_bias = false;
+};
+
+struct BnHost {
+    std::vector<float> mean, var;
+};
+
+}  // namespace
+
+struct kws_handle {
+    kws_model_desc d{};
+    int device = 0;
+    Plan plan = PLAN_FRONTEND_ONLY;
+    bool res8_eligible = false;
+    bool force_layerwise = false;
+
+    // front end
+    DevMem dft, melw, mel_lo, mel_hi;
+
+    // parameters
+    std::set<std::string> required, loaded;
+    bool dirty = true;
+    // ResNet
+    std::vector<ConvLayer> rconv;          // conv_0 .. conv_n  (layer-wise packing)
+    std::vector<BnHost> bn;                // bn_1 .. bn_n (index i-1)
+    DevMem bn_scale, bn_shift, bn_mean, bn_rstd;   // (n_layers, C) each, layer-wise path
+    DevMem out_w, out_b;
+    // fused res8
+    DevMem r8_w0, r8_apk, r8_mean, r8_rstd;
+    std::vector<float> r8_apk_host;
+    // CNN
+    std::vector<ConvLayer> cconv;          // conv_0 [, conv_1]
+    std::vector<ConvLayer> clin;           // lin_0, dnn_0, dnn_1, lin_1 (present ones, in order)
+    std::vector<std::string> clin_names;
+    int cnn_shape[3][3] = {};              // (C,H,W) after conv/pool stage i (index 0 = input)
+    size_t cnn_max_elems = 0;              // largest per-clip activation
+
+    // workspace
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev_model, ev_front;   // start/stop pairs
+    double acc_model_ms = 0, acc_front_ms = 0;
+    int acc_calls = 0;
+    const char* last_plan = "none";
+
+    ~kws_handle() {
+        for (auto e : ev_model) (void)hipEventDestroy(e);
+        for (auto e : ev_front) (void)hipEventDestroy(e);
+    }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- front end setup
+double hz_to_mel(double f) {
+    const double f_sp = 200.0 / 3.0, logstep = std::log(6.4) / 27.0;
+    return f >= 1000.0 ? 15.0 + std::log(f / 1000.0) / logstep : f / f_sp;
+}
+double mel_to_hz(double m) {
+    const double f_sp = 200.0 / 3.0, logstep = std::log(6.4) / 27.0;
+    return m >= 15.0 ? 1000.0 * std::exp(logstep * (m - 15.0)) : m * f_sp;
+}
+
+int setup_frontend(kws_handle* h) {
+    const kws_model_desc& d = h->d;
+    if (d.n_fft != FE_NFFT || d.hop_length != FE_HOP)
+        return fail(KWS_EUNSUPPORTED, "front end kernels are built for n_fft=480, hop_length=160");
+    if (d.n_mels <= 0 || d.n_mels > 256) return fail(KWS_EINVAL, "n_mels out of range");
+    // Slaney filterbank; double arithmetic, cast to fp32 like librosa's dtype=float32
+    const int nb = 1 + d.n_fft / 2;
+    std::vector<double> edges(d.n_mels + 2);
+    const double m0 = hz_to_mel(d.f_min), m1 = hz_to_mel(d.f_max);
+    for (int i = 0; i < d.n_mels + 2; ++i) edges[i] = mel_to_hz(m0 + (m1 - m0) * i / (d.n_mels + 1));
+    std::vector<float> wts((size_t)d.n_mels * FE_ROWS, 0.f);
+    std::vector<int> lo(d.n_mels), hi(d.n_mels);
+    for (int i = 0; i < d.n_mels; ++i) {
+        lo[i] = FE_ROWS;
+        hi[i] = 0;
+        const float enorm = (float)(2.0 / (edges[i + 2] - edges[i]));
+        for (int k = 0; k < nb; ++k) {
+            const double fk = (double)k * d.sample_rate / d.n_fft;
+            const double up = (fk - edges[i]) / (edges[i + 1] - edges[i]);
+            const double dn = (edges[i + 2] - fk) / (edges[i + 2] - edges[i + 1]);
+            const float wv = (float)std::max(0.0, std::min(up, dn)) * enorm;
+            if (wv != 0.f) {
+                if (k >= FE_ROWS)
+                    return fail(KWS_EUNSUPPORTED, "mel filterbank reaches past DFT bin 127 (f_max too high for this build)");
+                wts[(size_t)i * FE_ROWS + k] = wv;
+                lo[i] = std::min(lo[i], k);
+                hi[i] = std::max(hi[i], k + 1);
+            }
+        }
+        if (hi[i] <= lo[i]) lo[i] = hi[i] = 0;
+    }
+    std::vector<float> tab;
+    build_dft_table(tab);
+    int rc;
+    if ((rc = h->dft.upload(tab.data(), tab.size() * sizeof(float)))) return rc;
+    if ((rc = h->melw.upload(wts.data(), wts.size() * sizeof(float)))) return rc;
+    if ((rc = h->mel_lo.upload(lo.data(), lo.size() * sizeof(int)))) return rc;
+    if ((rc = h->mel_hi.upload(hi.data(), hi.size() * sizeof(int)))) return rc;
+    return KWS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- geometry helpers
+int conv_out(int n, int k, int s, int p, int dil) { return (n + 2 * p - (dil * (k - 1) + 1)) / s + 1; }
+
+void finish_geom(ConvGeom& g) {
+    g.kx_inner = g.Cin == 1 ? 1 : 0;
+    g.inner_steps = g.kx_inner ? (g.kw + 3) / 4 : (g.Cin + 3) / 4;
+    g.ksteps = g.kx_inner ? g.kh * g.inner_steps : g.kh * g.kw * g.inner_steps;
+    g.mtiles = (g.Cout + 15) / 16;
+    g.MT = choose_mt(g.mtiles);
+}
+
+ConvGeom make_geom(int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int relu) {
+    ConvGeom g{};
+    g.Cin = cin; g.Cout = cout; g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw; g.ph = ph; g.pw = pw; g.dh = dh; g.dw = dw;
+    g.relu = relu;
+    finish_geom(g);
+    return g;
+}
+
+void set_spatial(ConvGeom& g, int B, int H, int W) {
+    g.B = B; g.H = H; g.W = W;
+    g.Ho = conv_out(H, g.kh, g.sh, g.ph, g.dh);
+    g.Wo = conv_out(W, g.kw, g.sw, g.pw, g.dw);
+}
+
+int resnet_dilation(const kws_model_desc& d, int i) { return d.use_dilation ? 1 << ((i - 1) / 3) : 1; }
+
+int build_resnet(kws_handle* h) {
+    const kws_model_desc& d = h->d;
+    if (d.n_layers < 1 || d.n_feature_maps < 1 || d.n_labels < 1) return fail(KWS_EINVAL, "bad ResNet description");
+    const int C = d.n_feature_maps;
+    h->rconv.resize(d.n_layers + 1);
+    h->rconv[0].g = make_geom(1, C, 3, 3, 1, 1, 1, 1, 1, 1, 1);
+    h->required.insert("layers.conv_0.weight");
+    h->bn.resize(d.n_layers);
+    for (int i = 1; i <= d.n_layers; ++i) {
+        const int dil = resnet_dilation(d, i);
+        h->rconv[i].g = make_geom(C, C, 3, 3, 1, 1, dil, dil, dil, dil, 1);
+        h->rconv[i].g.accumulate = (i % 2 == 0);
+        const std::string s = std::to_string(i);
+        h->required.insert("layers.conv_" + s + ".weight");
+        h->required.insert("layers.bn_" + s + ".running_mean");
+        h->required.insert("layers.bn_" + s + ".running_var");
+    }
+    h->required.insert("layers.output.weight");
+    h->required.insert("layers.output.bias");
+    h->res8_eligible = d.n_layers == R8_LAYERS && C == R8_C && !d.use_dilation && d.pool_h == 4 && d.pool_w == 3 &&
+                       d.freq == 40 && d.n_labels <= 256;
+    if (h->res8_eligible) h->r8_apk_host.assign(R8_APK_FLOATS, 0.f);
+    return KWS_OK;
+}
+
+int build_cnn(kws_handle* h) {
+    const kws_model_desc& d = h->d;
+    if (d.n_conv < 1 || d.n_conv > 2 || d.time < 1 || d.freq < 1) return fail(KWS_EINVAL, "bad CNN description");
+    int C = 1, H = d.time, W = d.freq;
+    h->cnn_shape[0][0] = C; h->cnn_shape[0][1] = H; h->cnn_shape[0][2] = W;
+    h->cconv.resize(d.n_conv);
+    size_t mx = 0;
+    for (int i = 0; i < d.n_conv; ++i) {
+        const kws_conv_desc& c = d.conv[i];
+        if (c.out_channels < 1 || c.kernel_h < 1 || c.kernel_w < 1 || c.stride_h < 1 || c.stride_w < 1 ||
+            d.pool_kh[i] < 1 || d.pool_kw[i] < 1)
+            return fail(KWS_EINVAL, "bad conv/pool description");
+        ConvGeom g = make_geom(C, c.out_channels, c.kernel_h, c.kernel_w, c.stride_h, c.stride_w, 0, 0, 1, 1, 1);
+        set_spatial(g, 0, H, W);
+        if (g.Ho < 1 || g.Wo < 1) return fail(KWS_EINVAL, "conv kernel larger than its input");
+        h->cconv[i].g = g;
+        h->cconv[i].has_bias = true;
+        mx = std::max(mx, (size_t)g.Cout * g.Ho * g.Wo);
+        C = g.Cout;
+        H = g.Ho / d.pool_kh[i];
+        W = g.Wo / d.pool_kw[i];
+        if (H < 1 || W < 1) return fail(KWS_EINVAL, "pool kernel larger than its input");
+        h->cnn_shape[i + 1][0] = C; h->cnn_shape[i + 1][1] = H; h->cnn_shape[i + 1][2] = W;
+        const std::string s = std::to_string(i);
+        h->required.insert("layers.conv_" + s + ".weight");
+        h->required.insert("layers.conv_" + s + ".bias");
+    }
+    int feat = C * H * W;
+    mx = std::max(mx, (size_t)feat);
+    const int outs[4] = {d.lin0_out, d.dnn0_out, d.dnn1_out, d.n_labels};
+    const char* names[4] = {"lin_0", "dnn_0", "dnn_1", "lin_1"};
+    for (int i = 0; i < 4; ++i) {
+        if (outs[i] <= 0) continue;
+        ConvLayer L;
+        L.g = make_geom(1, outs[i], 1, feat, 1, 1, 0, 0, 1, 1, 0);
+        set_spatial(L.g, 0, 1, feat);
+        L.has_bias = true;
+        h->clin.push_back(std::move(L));
+        h->clin_names.push_back(names[i]);
+        h->required.insert(std::string("layers.") + names[i] + ".weight");
+        h->required.insert(std::string("layers.") + names[i] + ".bias");
+        feat = outs[i];
+        mx = std::max(mx, (size_t)feat);
+    }
+    h->cnn_max_elems = mx;
+    return KWS_OK;
+}
+
+int upload_packed(ConvLayer& L, const float* w) {
+    std::vector<float> pk;
+    pack_conv_weights(L.g, w, pk);
+    return L.apk.upload(pk.data(), pk.size() * sizeof(float));
+}
+
+// ---------------------------------------------------------------------------------------------- finalize (lazy)
+int finalize(kws_handle* h) {
+    if (!h->dirty) return KWS_OK;
+    for (const auto& r : h->required)
+        if (!h->loaded.count(r)) return fail(KWS_ENOWEIGHTS, "tensor not loaded: " + r);
+    if (h->plan == PLAN_RESNET) {
+        const int C = h->d.n_feature_maps, n = h->d.n_layers;
+        std::vector<float> sc((size_t)n * C), sf((size_t)n * C), mu((size_t)n * C), rs((size_t)n * C);
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < C; ++c) {
+                const double r = 1.0 / std::sqrt((double)h->bn[i].var[c] + 1e-5);
+                mu[(size_t)i * C + c] = h->bn[i].mean[c];
+                rs[(size_t)i * C + c] = (float)r;
+                sc[(size_t)i * C + c] = (float)r;
+                sf[(size_t)i * C + c] = (float)(-(double)h->bn[i].mean[c] * r);
+            }
+        int rc;
+        if ((rc = h->bn_scale.upload(sc.data(), sc.size() * 4))) return rc;
+        if ((rc = h->bn_shift.upload(sf.data(), sf.size() * 4))) return rc;
+        if ((rc = h->bn_mean.upload(mu.data(), mu.size() * 4))) return rc;
+        if ((rc = h->bn_rstd.upload(rs.data(), rs.size() * 4))) return rc;
+        if (h->res8_eligible) {
+            std::vector<float> m48((size_t)R8_LAYERS * 48, 0.f), r48((size_t)R8_LAYERS * 48, 0.f);
+            for (int i = 0; i < R8_LAYERS; ++i)
+                for (int c = 0; c < R8_C; ++c) {
+                    m48[(size_t)i * 48 + c] = mu[(size_t)i * C + c];
+                    r48[(size_t)i * 48 + c] = rs[(size_t)i * C + c];
+                }
+            if ((rc = h->r8_mean.upload(m48.data(), m48.size() * 4))) return rc;
+            if ((rc = h->r8_rstd.upload(r48.data(), r48.size() * 4))) return rc;
+            if ((rc = h->r8_apk.upload(h->r8_apk_host.data(), h->r8_apk_host.size() * 4))) return rc;
+        }
+    }
+    h->dirty = false;
+    return KWS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- sizes
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t feat_bytes(const kws_handle* h, int B, int T) { return align256((size_t)B * T * h->d.freq * sizeof(float)); }
+
+bool use_fused(const kws_handle* h, int T) {
+    return h->plan == PLAN_RESNET && h->res8_eligible && !h->force_layerwise && T == 101;
+}
+
+struct ResnetShape { int C, T, F, H, W; bool pooled; };
+ResnetShape resnet_shape(const kws_handle* h, int T) {
+    ResnetShape s{};
+    s.C = h->d.n_feature_maps; s.T = T; s.F = h->d.freq;
+    s.pooled = h->d.pool_h > 0 && h->d.pool_w > 0;
+    s.H = s.pooled ? T / h->d.pool_h : T;
+    s.W = s.pooled ? s.F / h->d.pool_w : s.F;
+    return s;
+}
+
+// clips per layer-wise launch: keep every activation tensor under 2^28 elements (1 GiB) and 32-bit indexable
+int chunk_clips(size_t per_clip_elems, int B) {
+    size_t cb = ((size_t)1 << 28) / std::max<size_t>(per_clip_elems, 1);
+    cb = std::max<size_t>(1, std::min<size_t>(cb, 1024));
+    return (int)std::min<size_t>(cb, (size_t)std::max(B, 1));
+}
+
+size_t act_bytes(const kws_handle* h, int B, int T) {
+    if (h->plan == PLAN_RESNET) {
+        if (use_fused(h, T)) return 0;
+        const ResnetShape s = resnet_shape(h, T);
+        const size_t full = (size_t)s.C * s.T * s.F, small = (size_t)s.C * s.H * s.W;
+        const int cb = chunk_clips(full, B);
+        return (s.pooled ? align256(full * cb * 4) : 0) + 2 * align256(small * cb * 4);
+    }
+    if (h->plan == PLAN_CNN) {
+        const int cb = chunk_clips(h->cnn_max_elems, B);
+        return 2 * align256(h->cnn_max_elems * cb * 4);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- profiling helpers
+int prof_mark(kws_handle* h, std::vector<hipEvent_t>& v, hipStream_t s) {
+    if (!h->prof) return KWS_OK;
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    v.push_back(e);
+    HIP_TRY(hipEventRecord(e, s));
+    return KWS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- model dispatch
+int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
+    const kws_model_desc& d = h->d;
+    const ResnetShape sh = resnet_shape(h, T);
+    if (sh.H < 1 || sh.W < 1) return fail(KWS_EINVAL, "feature map smaller than the pooling window");
+    const size_t full = (size_t)sh.C * sh.T * sh.F, small = (size_t)sh.C * sh.H * sh.W;
+    const int cb = chunk_clips(full, B);
+    float* bufA = nullptr;
+    if (sh.pooled) { bufA = (float*)ws; ws += align256(full * cb * 4); }
+    float* X = (float*)ws; ws += align256(small * cb * 4);
+    float* Y = (float*)ws;
+    const int C = sh.C;
+    for (int b0 = 0; b0 < B; b0 += cb) {
+        const int nb = std::min(cb, B - b0);
+        // conv_0 + ReLU (+ AvgPool)
+        ConvGeom g0 = h->rconv[0].g;
+        set_spatial(g0, nb, sh.T, sh.F);
+        ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr};
+        HIP_TRY(launch_conv(g0, a0, s));
+        if (sh.pooled) HIP_TRY(launch_pool(bufA, X, nb * C, sh.T, sh.F, d.pool_h, d.pool_w, 0, s));
+        // conv_i: odd i writes Y from X, even i accumulates into X from Y (prev_x lives in X)
+        for (int i = 1; i <= d.n_layers; ++i) {
+            ConvGeom g = h->rconv[i].g;
+            set_spatial(g, nb, sh.H, sh.W);
+            const bool even = (i % 2) == 0;
+            ConvArgs a{even ? Y : X, even ? X : Y, h->rconv[i].apk.as<float>(), nullptr,
+                       i > 1 ? h->bn_scale.as<float>() + (size_t)(i - 2) * C : nullptr,
+                       i > 1 ? h->bn_shift.as<float>() + (size_t)(i - 2) * C : nullptr};
+            HIP_TRY(launch_conv(g, a, s));
+        }
+        const float* fin = (d.n_layers % 2 == 0) ? X : Y;
+        HIP_TRY(launch_mean_linear(fin, logits + (size_t)b0 * d.n_labels, nb, C, sh.H * sh.W,
+                                   h->bn_mean.as<float>() + (size_t)(d.n_layers - 1) * C,
+                                   h->bn_rstd.as<float>() + (size_t)(d.n_layers - 1) * C, h->out_w.as<float>(),
+                                   h->out_b.as<float>(), d.n_labels, s));
+    }
+    return KWS_OK;
+}
+
+int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
+    const kws_model_desc& d = h->d;
+    if (T != d.time) return fail(KWS_EINVAL, "CNN was built for a different number of frames (config[\"time\"])");
+    const int cb = chunk_clips(h->cnn_max_elems, B);
+    float* P = (float*)ws;
+    float* Q = (float*)(ws + align256(h->cnn_max_elems * cb * 4));
+    auto other = [&](const float* c) -> float* { return c == P ? Q : P; };
+    for (int b0 = 0; b0 < B; b0 += cb) {
+        const int nb = std::min(cb, B - b0);
+        const float* cur = feat + (size_t)b0 * d.time * d.freq;
+        for (int i = 0; i < d.n_conv; ++i) {
+            ConvGeom g = h->cconv[i].g;
+            g.B = nb;
+            float* conv_out_buf = other(cur);
+            ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), h->cconv[i].bias.as<float>(), nullptr, nullptr};
+            HIP_TRY(launch_conv(g, a, s));
+            float* pooled = other(conv_out_buf);
+            HIP_TRY(launch_pool(conv_out_buf, pooled, nb * g.Cout, g.Ho, g.Wo, d.pool_kh[i], d.pool_kw[i], 1, s));
+            cur = pooled;
+        }
+        for (size_t i = 0; i < h->clin.size(); ++i) {
+            ConvGeom g = h->clin[i].g;
+            g.B = nb;
+            const bool last = i + 1 == h->clin.size();
+            float* dst = last ? logits + (size_t)b0 * d.n_labels : other(cur);
+            ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), h->clin[i].bias.as<float>(), nullptr, nullptr};
+            HIP_TRY(launch_conv(g, a, s));
+            cur = dst;
+        }
+    }
+    return KWS_OK;
+}
+
+int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws_act, hipStream_t s) {
+    int rc;
+    if ((rc = prof_mark(h, h->ev_model, s))) return rc;
+    if (h->plan == PLAN_RESNET) {
+        if (use_fused(h, T)) {
+            h->last_plan = "res8_fused";
+            Res8Params p{feat, logits, h->r8_w0.as<float>(), h->r8_apk.as<f32x4>(), h->r8_mean.as<float>(),
+                         h->r8_rstd.as<float>(), h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq,
+                         h->d.n_labels};
+            const int grid = std::min(B, 512);
+            HIP_TRY(launch_res8(p, grid, s));
+        } else {
+            h->last_plan = "layerwise";
+            if ((rc = run_resnet_layerwise(h, feat, B, T, logits, ws_act, s))) return rc;
+        }
+    } else if (h->plan == PLAN_CNN) {
+        h->last_plan = "layerwise";
+        if ((rc = run_cnn(h, feat, B, T, logits, ws_act, s))) return rc;
+    } else {
+        return fail(KWS_EUNSUPPORTED, "handle was created with family KWS_MODEL_NONE (front end only)");
+    }
+    return prof_mark(h, h->ev_model, s);
+}
+
+int check_ws(const kws_handle* h, size_t need) {
+    if (need == 0) return KWS_OK;
+    if (!h->ws || h->ws_bytes < need)
+        return fail(KWS_ENOWORKSPACE, "workspace too small: need " + std::to_string(need) + " bytes, have " +
+                                          std::to_string(h->ws_bytes));
+    return KWS_OK;
+}
+
+int strip_and_match(const char* name, std::string& out) {
+    if (!name) return fail(KWS_EINVAL, "null tensor name");
+    out = name;
+    if (out.rfind("module.", 0) == 0) out = out.substr(7);   // DataParallel prefix (reference run/test.py:69-70)
+    return KWS_OK;
+}
+
+}  // namespace
+
+// ================================================================================================== C ABI
+extern "C" {
+
+int kws_abi_version(void) { return KWS_ABI_VERSION; }
+const char* kws_last_error(void) { return g_err.c_str(); }
+
+int kws_create(const kws_model_desc* desc, kws_handle** out) {
+    if (!desc || !out) return fail(KWS_EINVAL, "null argument");
+    if (desc->struct_size != (int)sizeof(kws_model_desc)) return fail(KWS_EINVAL, "kws_model_desc size mismatch (ABI)");
+    if (desc->dtype != KWS_DTYPE_F32) return fail(KWS_EUNSUPPORTED, "only KWS_DTYPE_F32 is implemented");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(KWS_EHIP, "no HIP device available: the HIP path is mandatory, there is no CPU fallback");
+    std::unique_ptr<kws_handle> h(new (std::nothrow) kws_handle());
+    if (!h) return fail(KWS_ENOMEM, "out of host memory");
+    h->d = *desc;
+    HIP_TRY(hipGetDevice(&h->device));
+    const char* fl = std::getenv("KWS_FORCE_LAYERWISE");
+    h->force_layerwise = fl && fl[0] == '1';
+    int rc = setup_frontend(h.get());
+    if (rc) return rc;
+    switch (desc->family) {
+        case KWS_MODEL_NONE: h->plan = PLAN_FRONTEND_ONLY; break;
+        case KWS_MODEL_RESNET: h->plan = PLAN_RESNET; rc = build_resnet(h.get()); break;
+        case KWS_MODEL_CNN: h->plan = PLAN_CNN; rc = build_cnn(h.get()); break;
+        default: return fail(KWS_EINVAL, "unknown model family");
+    }
+    if (rc) return rc;
+    *out = h.release();
+    return KWS_OK;
+}
+
+void kws_destroy(kws_handle* h) { delete h; }
+
+int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, size_t bytes) {
+    if (!h || !host_ptr) return fail(KWS_EINVAL, "null argument");
+    std::string name;
+    int rc = strip_and_match(name_in, name);
+    if (rc) return rc;
+    if (name.size() > 19 && name.compare(name.size() - 19, 19, "num_batches_tracked") == 0) return KWS_OK;
+    if (!h->required.count(name)) return fail(KWS_EINVAL, "unexpected tensor name: " + name);
+    const float* src = static_cast<const float*>(host_ptr);
+    auto need = [&](size_t n) -> int {
+        if (bytes != n * sizeof(float))
+            return fail(KWS_EINVAL, name + ": expected " + std::to_string(n * 4) + " bytes, got " + std::to_string(bytes));
+        return KWS_OK;
+    };
+    char kind[32];
+    int idx = -1;
+    char field[32];
+    if (h->plan == PLAN_RESNET) {
+        const int C = h->d.n_feature_maps;
+        if (name == "layers.output.weight") {
+            if ((rc = need((size_t)h->d.n_labels * C))) return rc;
+            if ((rc = h->out_w.upload(src, bytes))) return rc;
+        } else if (name == "layers.output.bias") {
+            if ((rc = need(h->d.n_labels))) return rc;
+            if ((rc = h->out_b.upload(src, bytes))) return rc;
+        } else if (std::sscanf(name.c_str(), "layers.conv_%d.%31s", &idx, field) == 2) {
+            const size_t n = idx == 0 ? (size_t)C * 9 : (size_t)C * C * 9;
+            if ((rc = need(n))) return rc;
+            if ((rc = upload_packed(h->rconv[idx], src))) return rc;
+            if (h->res8_eligible) {
+                if (idx == 0) {
+                    std::vector<float> pairs(24 * 9 * 2, 0.f);   // [pair][tap][2], channels padded to 48
+                    for (int c = 0; c < R8_C; ++c)
+                        for (int t = 0; t < 9; ++t) pairs[((size_t)(c / 2) * 9 + t) * 2 + (c & 1)] = src[c * 9 + t];
+                    if ((rc = h->r8_w0.upload(pairs.data(), pairs.size() * 4))) return rc;
+                } else {
+                    pack_res8_layer(src, h->r8_apk_host.data() + (size_t)(idx - 1) * R8_GROUPS * 3 * 64 * 4);
+                }
+            }
+        } else if (std::sscanf(name.c_str(), "layers.bn_%d.%31s", &idx, field) == 2) {
+            if ((rc = need(C))) return rc;
+            std::vector<float>& dst = std::strcmp(field, "running_mean") == 0 ? h->bn[idx - 1].mean : h->bn[idx - 1].var;
+            dst.assign(src, src + C);
+        }
+    } else if (h->plan == PLAN_CNN) {
+        if (std::sscanf(name.c_str(), "layers.conv_%d.%31s", &idx, field) == 2) {
+            ConvLayer& L = h->cconv[idx];
+            if (std::strcmp(field, "weight") == 0) {
+                if ((rc = need((size_t)L.g.Cout * L.g.Cin * L.g.kh * L.g.kw))) return rc;
+                if ((rc = upload_packed(L, src))) return rc;
+            } else {
+                if ((rc = need(L.g.Cout))) return rc;
+                if ((rc = L.bias.upload(src, bytes))) return rc;
+            }
+        } else if (std::sscanf(name.c_str(), "layers.%31[^.].%31s", kind, field) == 2) {
+            size_t li = 0;
+            for (; li < h->clin_names.size(); ++li)
+                if (h->clin_names[li] == kind) break;
+            if (li == h->clin_names.size()) return fail(KWS_EINVAL, "unexpected tensor name: " + name);
+            ConvLayer& L = h->clin[li];
+            if (std::strcmp(field, "weight") == 0) {
+                if ((rc = need((size_t)L.g.Cout * L.g.kw))) return rc;
+                if ((rc = upload_packed(L, src))) return rc;
+            } else {
+                if ((rc = need(L.g.Cout))) return rc;
+                if ((rc = L.bias.upload(src, bytes))) return rc;
+            }
+        }
+    }
+    h->loaded.insert(name);
+    h->dirty = true;
+    return KWS_OK;
+}
+
+int kws_num_frames(const kws_handle* h, int n_samples) {
+    if (!h || n_samples < 0) return fail(KWS_EINVAL, "bad argument");
+    return 1 + n_samples / h->d.hop_length;
+}
+
+size_t kws_workspace_bytes(const kws_handle* h, int B, int T) {
+    if (!h || B < 0 || T < 1) return 0;
+    return feat_bytes(h, B, T) + act_bytes(h, B, T);
+}
+
+int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes) {
+    if (!h) return fail(KWS_EINVAL, "null handle");
+    if (d_ptr && (reinterpret_cast<uintptr_t>(d_ptr) & 255)) return fail(KWS_EINVAL, "workspace must be 256-byte aligned");
+    h->ws = d_ptr;
+    h->ws_bytes = d_ptr ? bytes : 0;
+    return KWS_OK;
+}
+
+int kws_mfcc(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_feat, void* stream) {
+    if (!h || !d_wav || !d_feat || B < 0) return fail(KWS_EINVAL, "bad argument");
+    if (n_samples <= FE_NFFT / 2) return fail(KWS_EINVAL, "clip shorter than the reflect padding (n_fft/2 + 1 samples needed)");
+    if (h->d.n_mels != h->d.freq && h->plan != PLAN_FRONTEND_ONLY) return fail(KWS_EINVAL, "n_mels != model frequency bins");
+    const int T = 1 + n_samples / FE_HOP;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    if ((rc = prof_mark(h, h->ev_front, s))) return rc;
+    FrontendParams p{d_wav, d_feat, h->dft.as<f32x4>(), h->melw.as<float>(), h->mel_lo.as<int>(), h->mel_hi.as<int>(),
+                     B, n_samples, T, h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES};
+    HIP_TRY(launch_frontend(p, s));
+    return prof_mark(h, h->ev_front, s);
+}
+
+int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits, void* stream) {
+    if (!h || !d_feat || !d_logits || B < 0 || T < 1) return fail(KWS_EINVAL, "bad argument");
+    int rc = finalize(h);
+    if (rc) return rc;
+    const size_t need = act_bytes(h, B, T);
+    if ((rc = check_ws(h, need))) return rc;
+    // activations use the TAIL of the workspace so that kws_forward_wav's feature block (the head) stays intact
+    char* ws_act = need ? static_cast<char*>(h->ws) + (h->ws_bytes - need) : nullptr;
+    if (ws_act) ws_act = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(ws_act) & ~(uintptr_t)255);
+    return run_model(h, static_cast<const float*>(d_feat), B, T, static_cast<float*>(d_logits), ws_act,
+                     static_cast<hipStream_t>(stream));
+}
+
+int kws_forward_wav(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_logits, void* stream) {
+    if (!h || !d_wav || !d_logits || B < 0) return fail(KWS_EINVAL, "bad argument");
+    int rc = finalize(h);
+    if (rc) return rc;
+    const int T = 1 + n_samples / FE_HOP;
+    const size_t fb = feat_bytes(h, B, T), ab = act_bytes(h, B, T);
+    if ((rc = check_ws(h, fb + ab))) return rc;
+    float* feat = static_cast<float*>(h->ws);
+    if ((rc = kws_mfcc(h, d_wav, B, n_samples, feat, stream))) return rc;
+    char* ws_act = ab ? static_cast<char*>(h->ws) + fb : nullptr;
+    return run_model(h, feat, B, T, d_logits, ws_act, static_cast<hipStream_t>(stream));
+}
+
+int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target, int B, int64_t* d_stats,
+                   double* d_loss_sum, void* stream) {
+    if (!h || !d_logits || !d_target || !d_stats || !d_loss_sum || B < 0) return fail(KWS_EINVAL, "bad argument");
+    HIP_TRY(launch_eval_tail(d_logits, d_target, B, h->d.n_labels, d_stats, d_loss_sum, static_cast<hipStream_t>(stream)));
+    return KWS_OK;
+}
+
+const char* kws_plan_name(const kws_handle* h) { return h ? h->last_plan : "none"; }
+
+int kws_profile_enable(kws_handle* h, int enable) {
+    if (!h) return fail(KWS_EINVAL, "null handle");
+    h->prof = enable != 0;
+    return KWS_OK;
+}
+
+int kws_profile_read(kws_handle* h, double* model_ms, double* frontend_ms, int* calls) {
+    if (!h) return fail(KWS_EINVAL, "null handle");
+    auto drain = [&](std::vector<hipEvent_t>& v, double& acc) -> int {
+        for (size_t i = 0; i + 1 < v.size(); i += 2) {
+            HIP_TRY(hipEventSynchronize(v[i + 1]));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, v[i], v[i + 1]));
+            acc += ms;
+        }
+        for (auto e : v) (void)hipEventDestroy(e);
+        v.clear();
+        return KWS_OK;
+    };
+    const int ncalls = (int)(h->ev_model.size() / 2);
+    int rc;
+    if ((rc = drain(h->ev_model, h->acc_model_ms))) return rc;
+    if ((rc = drain(h->ev_front, h->acc_front_ms))) return rc;
+    if (model_ms) *model_ms = h->acc_model_ms;
+    if (frontend_ms) *frontend_ms = h->acc_front_ms;
+    if (calls) *calls = ncalls;
+    h->acc_model_ms = h->acc_front_ms = 0;
+    return KWS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Internal declarations shared by the C-ABI translation unit and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/kws.h"
+
+namespace kws {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------- front end (frontend.hip)
+constexpr int FE_NFFT = 480;
+constexpr int FE_HOP = 160;
+constexpr int FE_ROWS = 128;        // DFT bins 0..127 computed per workgroup (4 waves x 32 rows)
+constexpr int FE_NT = 7;            // 16-frame column tiles per workgroup chunk
+constexpr int FE_FRAMES = FE_NT * 16;
+constexpr int FE_S4 = 15;           // 60 k-steps of 4 folded sample pairs, packed 4 steps per float4
+constexpr int FE_PSTRIDE = 116;     // row stride (words) of the power tile in LDS
+constexpr size_t FE_TABLE_FLOATS = (size_t)4 * FE_S4 * 4 * 64 * 4;
+
+struct FrontendParams {
+    const float* wav;     // (B, n_samples)
+    float* feat;          // (B, T, n_mels)
+    const f32x4* dft;     // packed windowed cos/sin table, FE_TABLE_FLOATS floats
+    const float* melw;    // (n_mels, FE_ROWS) dense mel weights over bins 0..127
+    const int* mel_lo;    // first / one-past-last non-zero bin per mel band
+    const int* mel_hi;
+    int B, n_samples, T, n_mels, chunks;
+};
+size_t frontend_lds_bytes(int T);
+hipError_t launch_frontend(const FrontendParams& p, hipStream_t s);
+void build_dft_table(std::vector<float>& out);  // host side, double precision trig
+
+// ---------------------------------------------------------------- fused res8 (res8_fused.hip)
+constexpr int R8_C = 45, R8_H = 25, W8_W = 13, R8_NPOS = 325;
+constexpr int R8_RS = 14;           // LDS row stride: 13 columns + one shared zero halo column
+constexpr int R8_CS = 400;          // LDS channel stride (27*14+1 = 379 used, 400 = 16 mod 32 banks)
+constexpr int R8_LAYERS = 6;
+constexpr int R8_GROUPS = 28;       // 9 taps x 3 float4 groups (11 steps + 1 pad) + 1 leftover group
+constexpr size_t R8_APK_FLOATS = (size_t)R8_LAYERS * R8_GROUPS * 3 * 64 * 4;
+
+struct Res8Params {
+    const float* feat;    // (B, 101, 40)
+    float* logits;        // (B, n_labels)
+    const float* w0;      // conv_0 weight (45, 9)
+    const f32x4* apk;     // packed conv_1..6 weights
+    const float* bn_mean; // (6, 48)
+    const float* bn_rstd; // (6, 48)
+    const float* out_w;   // (n_labels, 45)
+    const float* out_b;   // (n_labels)
+    int B, T, F, n_labels;
+};
+size_t res8_lds_bytes();
+hipError_t launch_res8(const Res8Params& p, int grid, hipStream_t s);
+void pack_res8_layer(const float* w /*45x45x3x3*/, float* dst /*R8_GROUPS*3*64*4*/);
+
+// ---------------------------------------------------------------- layer-wise kernels (layerwise.hip)
+struct ConvGeom {
+    int B;                 // clips in this launch
+    int Cin, H, W;         // input map
+    int Cout, Ho, Wo;      // output map
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    int kx_inner;          // 1: K = (ky, kx padded to 4), needs Cin == 1;  0: K = (ky, kx, cin padded to 4)
+    int inner_steps;       // ceil(kw/4) or ceil(Cin/4)
+    int ksteps;            // kh*inner_steps (kx_inner) or kh*kw*inner_steps
+    int mtiles;            // ceil(Cout/16)
+    int MT;                // m-tiles per wave (1..4); grid.y = ceil(mtiles/MT)
+    int relu, accumulate;  // epilogue: ReLU; out += value (residual kept in the output buffer)
+};
+struct ConvArgs {
+    const float* in;       // (B, Cin, H, W)
+    float* out;            // (B, Cout, Ho, Wo)
+    const float* apk;      // packed weights [mgroup][kstep][MT][64]
+    const float* bias;     // (Cout) or nullptr
+    const float* in_scale; // BN-on-load: x*scale[c] + shift[c] for in-bounds taps; nullptr = identity
+    const float* in_shift;
+};
+hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, hipStream_t s);
+void pack_conv_weights(const ConvGeom& g, const float* w /*Cout,Cin,kh,kw*/, std::vector<float>& dst);
+int choose_mt(int mtiles);
+
+hipError_t launch_pool(const float* in, float* out, int planes /*B*C*/, int H, int W, int kh, int kw, int is_max,
+                       hipStream_t s);
+// logits[b] = W * ((mean_hw(x[b]) - mean) * rstd) + bias     (mean/rstd may be nullptr = identity)
+hipError_t launch_mean_linear(const float* x, float* logits, int B, int C, int HW, const float* mean,
+                              const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s);
+hipError_t launch_eval_tail(const float* logits, const int64_t* target, int B, int n_labels, int64_t* stats,
+                            double* loss_sum, hipStream_t s);
+
+}  // namespace kws

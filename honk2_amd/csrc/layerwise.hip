@@ -1,0 +1,328 @@
+// Layer-by-layer kernels for every model the fused res8 path does not cover: res15 / res26 / narrow variants /
+// hey_snips (reference model/resnet.py:38-60, any n_layers, n_feature_maps, dilation, pool) and the cnn-* family
+// (reference model/cnn.py:79-107: rectangular valid convs with stride and bias, MaxPool, up to four Linears).
+//
+// One implicit-GEMM kernel on the fp32 matrix cores (v_mfma_f32_16x16x4_f32) serves all of them:
+//   M = output channels (tiles of 16, MT tiles per wave), N = B*Ho*Wo output positions flattened over the batch
+//   (64 per wave, 256 per workgroup), K = taps x input channels.
+//   * K order (ky, kx, cin padded to 4) for Cin > 1: within a tap the four k-slots of an MFMA are four consecutive
+//     input channels, so tap geometry / bounds are computed once per tap and the inner loop is one predicated
+//     global load + (optional BatchNorm-on-load FMA) per B fragment.
+//   * K order (ky, kx padded to 4) for Cin == 1 (every conv_0, and every Linear, which is run as a 1 x K "conv"
+//     over the flattened feature vector): the four k-slots are four consecutive columns, i.e. contiguous memory.
+//   * BatchNorm of the PREVIOUS layer is applied on load (zero padding stays exactly zero, as in the reference
+//     where padding is applied after BN); ReLU, bias and the residual add are fused into the epilogue.  With
+//     `accumulate` the output buffer already holds prev_x and becomes the new prev_x, so a ResNet needs two
+//     activation buffers.
+//   Activations are fp32 (B, C, H, W) in the caller-provided workspace.
+#include "kws_internal.h"
+
+namespace kws {
+
+template <int MT, bool KX>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int g = lane >> 4;
+    const int pcol = lane & 15;
+    const int npc = gm.Ho * gm.Wo;
+    const long long ntot = (long long)gm.B * npc;
+    const long long n0 = ((long long)blockIdx.x * 4 + w) * 64;
+    const int hw = gm.H * gm.W;
+
+    bool valid[4];
+    int iy0[4], ix0[4], inb[4], pos[4], bidx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long n = n0 + 16 * j + pcol;
+        valid[j] = n < ntot;
+        const long long nn = valid[j] ? n : ntot - 1;
+        const int b = (int)(nn / npc);
+        const int ps = (int)(nn - (long long)b * npc);
+        const int oy = ps / gm.Wo;
+        const int ox = ps - oy * gm.Wo;
+        bidx[j] = b;
+        pos[j] = ps;
+        iy0[j] = oy * gm.sh - gm.ph;
+        ix0[j] = ox * gm.sw - gm.pw;
+        inb[j] = b * gm.Cin * hw;
+    }
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* A = a.apk + (size_t)blockIdx.y * gm.ksteps * MT * 64 + lane;
+    const float* __restrict__ in = a.in;
+
+    if (KX) {
+        for (int ky = 0; ky < gm.kh; ++ky) {
+            bool rowok[4];
+            int rowbase[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = iy0[j] + ky * gm.dh;
+                rowok[j] = valid[j] && iy >= 0 && iy < gm.H;
+                rowbase[j] = inb[j] + iy * gm.W;
+            }
+            for (int xg = 0; xg < gm.inner_steps; ++xg) {
+                const int kx = 4 * xg + g;
+                const bool kok = kx < gm.kw;
+                float am[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) am[m] = A[m * 64];
+                A += MT * 64;
+                float bv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ix = ix0[j] + kx * gm.dw;
+                    const bool ok = rowok[j] && kok && ix >= 0 && ix < gm.W;
+                    const float v = in[ok ? rowbase[j] + ix : 0];
+                    bv[j] = ok ? v : 0.f;
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[m], bv[j], acc[m][j], 0, 0, 0);
+            }
+        }
+    } else {
+        const bool bn = a.in_scale != nullptr;
+        for (int ky = 0; ky < gm.kh; ++ky)
+            for (int kx = 0; kx < gm.kw; ++kx) {
+                bool ok[4];
+                int base[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int iy = iy0[j] + ky * gm.dh;
+                    const int ix = ix0[j] + kx * gm.dw;
+                    ok[j] = valid[j] && iy >= 0 && iy < gm.H && ix >= 0 && ix < gm.W;
+                    base[j] = ok[j] ? inb[j] + iy * gm.W + ix : 0;
+                }
+                for (int cg = 0; cg < gm.inner_steps; ++cg) {
+                    const int c = 4 * cg + g;
+                    const bool cok = c < gm.Cin;
+                    const int coff = cok ? c * hw : 0;
+                    float sc = 1.f, sf = 0.f;
+                    if (bn) {
+                        sc = a.in_scale[cok ? c : 0];
+                        sf = a.in_shift[cok ? c : 0];
+                    }
+                    float am[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) am[m] = A[m * 64];
+                    A += MT * 64;
+                    float bv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool k = ok[j] && cok;
+                        const float v = in[k ? base[j] + coff : 0];
+                        bv[j] = k ? fmaf(v, sc, sf) : 0.f;
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[m], bv[j], acc[m][j], 0, 0, 0);
+                }
+            }
+    }
+
+    // epilogue: D[row = 4g + r][col = pcol]; rows are output channels
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = ((int)blockIdx.y * MT + m) * 16 + 4 * g + r;
+            if (co >= gm.Cout) continue;
+            const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!valid[j]) continue;
+                float v = acc[m][j][r] + bias;
+                if (gm.relu) v = fmaxf(v, 0.f);
+                const size_t idx = ((size_t)bidx[j] * gm.Cout + co) * npc + pos[j];
+                if (gm.accumulate) v += a.out[idx];
+                a.out[idx] = v;
+            }
+        }
+}
+
+int choose_mt(int mtiles) {
+    int best = 1, waste = 1 << 30;
+    for (int mt = 4; mt >= 1; --mt) {
+        const int wst = (mtiles + mt - 1) / mt * mt - mtiles;
+        if (wst < waste) {
+            waste = wst;
+            best = mt;
+        }
+    }
+    return best;
+}
+
+template <int MT>
+static hipError_t launch_conv_mt(const ConvGeom& g, const ConvArgs& a, hipStream_t s) {
+    const long long ntot = (long long)g.B * g.Ho * g.Wo;
+    dim3 grid((unsigned)((ntot + 255) / 256), (unsigned)((g.mtiles + MT - 1) / MT));
+    if (g.kx_inner)
+        hipLaunchKernelGGL((conv_igemm_kernel<MT, true>), grid, dim3(256), 0, s, g, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<MT, false>), grid, dim3(256), 0, s, g, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, hipStream_t s) {
+    if (g.B <= 0) return hipSuccess;
+    switch (g.MT) {
+        case 1: return launch_conv_mt<1>(g, a, s);
+        case 2: return launch_conv_mt<2>(g, a, s);
+        case 3: return launch_conv_mt<3>(g, a, s);
+        case 4: return launch_conv_mt<4>(g, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// Host: weights (Cout, Cin, kh, kw) -> [mgroup][kstep][MT][lane]; lane = (k-slot g << 4) | row.
+void pack_conv_weights(const ConvGeom& g, const float* w, std::vector<float>& dst) {
+    const int mgroups = (g.mtiles + g.MT - 1) / g.MT;
+    dst.assign((size_t)mgroups * g.ksteps * g.MT * 64, 0.f);
+    for (int mg = 0; mg < mgroups; ++mg)
+        for (int ks = 0; ks < g.ksteps; ++ks)
+            for (int m = 0; m < g.MT; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = (mg * g.MT + m) * 16 + (lane & 15);
+                    const int slot = lane >> 4;
+                    int c, ky, kx;
+                    if (g.kx_inner) {
+                        ky = ks / g.inner_steps;
+                        kx = 4 * (ks % g.inner_steps) + slot;
+                        c = 0;
+                    } else {
+                        const int tap = ks / g.inner_steps;
+                        ky = tap / g.kw;
+                        kx = tap % g.kw;
+                        c = 4 * (ks % g.inner_steps) + slot;
+                    }
+                    float v = 0.f;
+                    if (co < g.Cout && c < g.Cin && kx < g.kw && ky < g.kh)
+                        v = w[(((size_t)co * g.Cin + c) * g.kh + ky) * g.kw + kx];
+                    dst[(((size_t)mg * g.ksteps + ks) * g.MT + m) * 64 + lane] = v;
+                }
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+// AvgPool2d / MaxPool2d with stride == kernel, floor mode (reference model/resnet.py:34, model/cnn.py:30,43).
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                   long long total, int H, int W, int Ho, int Wo, int kh, int kw,
+                                                   int is_max) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % Wo);
+    const long long t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const long long plane = t / Ho;
+    const float* src = in + (plane * H + (long long)oy * kh) * W + (long long)ox * kw;
+    float v = is_max ? -INFINITY : 0.f;
+    for (int y = 0; y < kh; ++y)
+        for (int x = 0; x < kw; ++x) {
+            const float s = src[y * W + x];
+            v = is_max ? fmaxf(v, s) : v + s;
+        }
+    out[i] = is_max ? v : v / (float)(kh * kw);
+}
+
+hipError_t launch_pool(const float* in, float* out, int planes, int H, int W, int kh, int kw, int is_max,
+                       hipStream_t s) {
+    const int Ho = H / kh, Wo = W / kw;
+    const long long total = (long long)planes * Ho * Wo;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, H, W, Ho,
+                       Wo, kh, kw, is_max);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ mean + linear
+// ResNet tail (reference model/resnet.py:57-59) with the last BatchNorm folded in: mean(BN(x)) == BN(mean(x)).
+__global__ __launch_bounds__(256) void mean_linear_kernel(const float* __restrict__ x, float* __restrict__ logits,
+                                                          int C, int HW, const float* mean, const float* rstd,
+                                                          const float* __restrict__ wt, const float* __restrict__ bias,
+                                                          int n_out) {
+    extern __shared__ float mv[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    for (int c = w; c < C; c += 4) {
+        const float* src = x + ((size_t)b * C + c) * HW;
+        float s = 0.f;
+        for (int i = lane; i < HW; i += 64) s += src[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) {
+            float m = s / (float)HW;
+            if (mean) m = (m - mean[c]) * rstd[c];
+            mv[c] = m;
+        }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < n_out; o += 256) {
+        float v = 0.f;
+        for (int c = 0; c < C; ++c) v = fmaf(wt[o * C + c], mv[c], v);
+        logits[(size_t)b * n_out + o] = v + bias[o];
+    }
+}
+
+hipError_t launch_mean_linear(const float* x, float* logits, int B, int C, int HW, const float* mean,
+                              const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mean_linear_kernel, dim3((unsigned)B), dim3(256), (size_t)C * sizeof(float), s, x, logits, C,
+                       HW, mean, rstd, w, bias, n_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ evaluation tail
+// ce_loss (loss_function.py:6-9) + Acc.accumulate (metric/acc.py:14-24) + PerClassAcc.accumulate
+// (metric/per_class_acc.py:14-45) in one pass: stats = [correct, total, per-class correct[n], per-class total[n]].
+__global__ __launch_bounds__(256) void eval_tail_kernel(const float* __restrict__ logits,
+                                                        const int64_t* __restrict__ target, int B, int n,
+                                                        unsigned long long* stats, double* loss_sum) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    double loss = 0.0;
+    if (b < B) {
+        const float* z = logits + (size_t)b * n;
+        int arg = 0;
+        float zmax = z[0];
+        for (int i = 1; i < n; ++i)
+            if (z[i] > zmax) {   // first maximum wins, as torch.argmax
+                zmax = z[i];
+                arg = i;
+            }
+        double se = 0.0;
+        for (int i = 0; i < n; ++i) se += exp((double)z[i] - (double)zmax);
+        const int t = (int)target[b];
+        loss = log(se) - ((double)z[t] - (double)zmax);
+        const bool hit = arg == t;
+        atomicAdd(&stats[1], 1ull);
+        atomicAdd(&stats[2 + n + t], 1ull);
+        if (hit) {
+            atomicAdd(&stats[0], 1ull);
+            atomicAdd(&stats[2 + t], 1ull);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) loss += __shfl_xor(loss, off);
+    if ((threadIdx.x & 63) == 0 && loss != 0.0) atomicAdd(loss_sum, loss);
+}
+
+hipError_t launch_eval_tail(const float* logits, const int64_t* target, int B, int n_labels, int64_t* stats,
+                            double* loss_sum, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(eval_tail_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, logits, target, B,
+                       n_labels, reinterpret_cast<unsigned long long*>(stats), loss_sum);
+    return hipGetLastError();
+}
+
+}  // namespace kws

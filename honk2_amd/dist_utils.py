@@ -1,0 +1,55 @@
+"""Data-parallel sharding helpers: one process per GPU, clips split contiguously, logits all-gathered (RCCL).
+
+The reference's only multi-GPU mechanism is ``torch.nn.DataParallel`` (``run/test.py:69-70``): scatter the batch,
+run replicas, gather outputs on device 0.  Clips are independent on this path (BN is in eval mode), so here each
+rank owns a contiguous slice and the single collective is an all-gather of the (B/G, n_labels) logits.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, rank, world):
+    """Contiguous, balanced split: the first n % world ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    n = int(os.environ.get("WORLD_SIZE", "1"))
+    if n <= 1 or dist.is_initialized():
+        return world()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend)
+    return world()
+
+
+def all_gather_rows(local, counts=None):
+    """Concatenate per-rank row blocks in rank order.  `counts` (rows per rank) allows ragged shards."""
+    rank, n = world()
+    if n == 1:
+        return local
+    if counts is None:
+        out = torch.empty((n * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    width = max(counts)
+    padded = local
+    if local.shape[0] < width:
+        pad = torch.zeros((width - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded = torch.cat([local, pad], 0)
+    parts = [torch.empty_like(padded) for _ in range(n)]
+    dist.all_gather(parts, padded.contiguous())
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], 0)

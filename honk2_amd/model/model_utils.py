@@ -1,0 +1,103 @@
+"""Model base class and parameter containers.
+
+``BaseModel`` keeps the reference's API (``model/model_utils.py:6-11``: ``num_params``,
+``num_trainable_params``) on top of ``torch.nn.Module`` so ``.eval()``, ``.to()``, ``.state_dict()`` and
+``.load_state_dict()`` behave as in the reference.  The modules below only HOLD tensors under the reference's
+state-dict key names (``layers.conv_3.weight``, ``layers.bn_3.running_var`` ...); they have no forward of their
+own, because the whole forward pass is one call into the HIP library (``kws_forward``).
+Initialisation draws from the torch RNG in the same order and with the same distributions as the
+``nn.Conv2d`` / ``nn.Linear`` modules the reference builds, so ``torch.manual_seed(s); Model(cfg)`` yields the
+same weights as the reference.
+"""
+import ctypes as C
+import math
+from abc import ABC
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class ConvParams(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, bias):
+        super().__init__()
+        kh, kw = kernel_size
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kh, kw))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(in_channels * kh * kw)
+            self.bias = nn.Parameter(torch.empty(out_channels))
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class LinearParams(nn.Module):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(in_features)
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class BatchNormStats(nn.Module):
+    """Running statistics of ``nn.BatchNorm2d(C, affine=False)`` (eval mode only, eps = 1e-5)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.register_buffer("running_mean", torch.zeros(channels))
+        self.register_buffer("running_var", torch.ones(channels))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class BaseModel(ABC, nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._engine = None
+        self._engine_key = None
+
+    def num_params(self):
+        return sum(p.numel() for p in self.parameters())
+
+    def num_trainable_params(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    # ------------------------------------------------------------------ HIP engine plumbing
+    def _make_desc(self):
+        raise NotImplementedError
+
+    def _weights_key(self):
+        return tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
+
+    def engine(self):
+        """The kws_handle for this model with the current weights loaded (re-uploaded when they change)."""
+        if self._engine is None:
+            self._engine = _lib.Engine(self._make_desc())
+            self._engine_key = None
+        key = self._weights_key()
+        if key != self._engine_key:
+            for name, tensor in self.state_dict().items():
+                self._engine.load_tensor(name, tensor)
+            self._engine_key = key
+        return self._engine
+
+    def _require_eval(self):
+        if self.training:
+            raise RuntimeError("honk2_amd models are inference-only: call model.eval() first "
+                               "(BatchNorm uses running statistics, dropout is the identity)")
+
+    def forward(self, x):
+        """(B, T, F) float32 features on the GPU -> (B, n_labels) logits (one ``kws_forward`` call)."""
+        self._require_eval()
+        with torch.no_grad():
+            return self.engine().forward(x)
+
+    def forward_wav(self, wav, out=None):
+        """(B, n_samples) float32 waveforms on the GPU -> logits, front end fused in (``kws_forward_wav``)."""
+        self._require_eval()
+        with torch.no_grad():
+            return self.engine().forward_wav(wav, out)
+
+    def plan_name(self):
+        return self.engine().plan_name()

@@ -1,0 +1,131 @@
+/*
+ * kws.h - C ABI of the MI355X-native keyword-spotting inference path (libkws_hip.so).
+ *
+ * This is the drop-in boundary for honk2's batched inference hot path
+ * (SURVEY.md section 8b).  Every entry point names the reference interface it
+ * replaces (paths relative to the honk2 repository):
+ *
+ *   kws_mfcc          <- AudioProcessor.compute_mfccs        utils/audio_processor.py:18-30
+ *                        looped per clip by collate_fn        data_loader/audio_data_loader.py:23-35
+ *   kws_forward       <- ResNet.forward / CNN.forward        model/resnet.py:38-60, model/cnn.py:79-107
+ *   kws_forward_wav   <- collate_fn + model(data)            run/test.py:22-26
+ *   kws_create        <- ResNet.__init__ / CNN.__init__      model/resnet.py:11-36, model/cnn.py:12-77
+ *                        + AudioProcessor.__init__            utils/audio_processor.py:8-16
+ *   kws_load_weights  <- model.load_state_dict               utils/workspace.py:58-61
+ *   kws_eval_batch    <- loss_fn + metric.accumulate          run/test.py:28-33, loss_function.py:6-9,
+ *                                                             metric/acc.py:14-24, metric/per_class_acc.py:14-45
+ *
+ * Conventions
+ *   - plain C types only; device pointers are raw `void*`/`float*` (the caller owns them: the
+ *     library BORROWS them for the duration of the call and never frees them).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every compute call is
+ *     asynchronous on that stream and performs no host synchronisation and no allocation, so a call
+ *     sequence can be captured into a hipGraph.
+ *   - every function returns 0 (KWS_OK) or a negative KWS_E* code; kws_last_error() returns a
+ *     thread-local human-readable message for the last failure on the calling thread.
+ *   - a handle is bound to the HIP device that was current at kws_create and is not re-entrant
+ *     (one in-flight call per handle); distinct handles are independent.
+ *   - all arithmetic is fp32 (KWS_DTYPE_F32): fp32-input MFMA + fp32 VALU, fp32 accumulation.
+ */
+#ifndef KWS_H_
+#define KWS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KWS_ABI_VERSION 1
+
+enum {
+    KWS_OK = 0,
+    KWS_EINVAL = -1,       /* bad argument / shape mismatch                         */
+    KWS_ENOMEM = -2,       /* host or device allocation failed (create/load only)  */
+    KWS_EUNSUPPORTED = -3, /* configuration outside what the kernels implement     */
+    KWS_ENOWORKSPACE = -4, /* workspace missing or too small for this call         */
+    KWS_ENOWEIGHTS = -5,   /* forward called before every tensor was loaded        */
+    KWS_EHIP = -6          /* a HIP runtime call failed (message has the hipError) */
+};
+
+enum { KWS_MODEL_NONE = 0, KWS_MODEL_RESNET = 1, KWS_MODEL_CNN = 2 };
+enum { KWS_DTYPE_F32 = 0 };
+
+typedef struct kws_conv_desc {
+    int32_t out_channels;
+    int32_t kernel_h, kernel_w; /* (time, frequency) */
+    int32_t stride_h, stride_w;
+} kws_conv_desc;
+
+/* Mirrors the reference's JSON `model.config` (config/resnet/res8.json:3-14, config/cnn/cnn-trad-pool2.json)
+ * plus the AudioProcessor constructor arguments (utils/audio_processor.py:8). */
+typedef struct kws_model_desc {
+    int32_t struct_size; /* sizeof(kws_model_desc), ABI check */
+    int32_t family;      /* KWS_MODEL_*; KWS_MODEL_NONE = front end only */
+    int32_t dtype;       /* KWS_DTYPE_F32 */
+    int32_t n_labels;
+    int32_t time;        /* frames of the feature map (CNN: config["time"]; ResNet: nominal, any T accepted) */
+    int32_t freq;        /* config["frequency"] / n_mels (40) */
+    /* ResNet */
+    int32_t n_layers, n_feature_maps, use_dilation;
+    int32_t pool_h, pool_w; /* 0,0 = no "pool" key */
+    /* CNN */
+    int32_t n_conv; /* 1 or 2 */
+    kws_conv_desc conv[2];
+    int32_t pool_kh[2], pool_kw[2];
+    int32_t lin0_out, dnn0_out, dnn1_out; /* 0 = layer absent */
+    /* front end */
+    int32_t sample_rate, n_fft, hop_length, n_mels;
+    float f_min, f_max;
+} kws_model_desc;
+
+typedef struct kws_handle kws_handle;
+
+/* Build the execution plan and allocate the (empty) device-side parameter store. */
+int kws_create(const kws_model_desc* desc, kws_handle** out);
+void kws_destroy(kws_handle* h);
+
+/* Copy one state-dict tensor (fp32, contiguous, reference key name such as "layers.conv_3.weight",
+ * "layers.bn_3.running_var", "layers.output.bias"; a leading "module." is ignored) from HOST memory and
+ * re-pack it into the kernel's layout.  `bytes` must equal the tensor's size.  "…num_batches_tracked" is
+ * accepted and ignored.  Synchronous. */
+int kws_load_weights(kws_handle* h, const char* name, const void* host_ptr, size_t bytes);
+
+/* Device scratch the compute calls need for a batch of B clips whose feature maps have T frames. */
+size_t kws_workspace_bytes(const kws_handle* h, int B, int T);
+int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes);
+
+/* Number of feature frames for n_samples input samples: 1 + n_samples / hop_length. */
+int kws_num_frames(const kws_handle* h, int n_samples);
+
+/* wav (B, n_samples) fp32 -> feat (B, T, n_mels) fp32, feat[b,t,f] = 2*ln(mel[f,t]) (0 where mel == 0). */
+int kws_mfcc(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_feat, void* stream);
+
+/* feat (B, T, freq) fp32 -> logits (B, n_labels) fp32. */
+int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits, void* stream);
+
+/* wav (B, n_samples) fp32 -> logits (B, n_labels) fp32 (feature maps stay in the workspace). */
+int kws_forward_wav(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_logits, void* stream);
+
+/* Evaluation tail, fused: adds to d_stats (int64[2 + 2*n_labels] = correct, total, per-class correct[n],
+ * per-class total[n]) and to d_loss_sum (double[1]: sum over clips of the cross-entropy, natural log). */
+int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target, int B,
+                   int64_t* d_stats, double* d_loss_sum, void* stream);
+
+/* Which execution plan the handle uses, e.g. "res8_fused" or "layerwise". */
+const char* kws_plan_name(const kws_handle* h);
+
+/* Optional in-library timing of the dominant kernel: when enabled every kws_forward* call brackets the model
+ * kernel(s) with hipEvents on the caller's stream.  kws_profile_read synchronises those events, returns the
+ * accumulated milliseconds and launch count since the last read, and resets them. */
+int kws_profile_enable(kws_handle* h, int enable);
+int kws_profile_read(kws_handle* h, double* model_ms, double* frontend_ms, int* calls);
+
+const char* kws_last_error(void);
+int kws_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KWS_H_ */

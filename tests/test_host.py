@@ -1,0 +1,151 @@
+"""CPU: host logic (registry, config plumbing, shapes, C-ABI loading) -- no compute calls."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import honk2_amd
+from conftest import GOLDEN, ROOT, golden_model_files, load_golden_model
+from honk2_amd import _lib
+from honk2_amd.utils import (calculate_conv_output_size, calculate_pool_output_size, find_cls, register_cls)
+from honk2_amd.utils.trie import Trie
+
+
+def test_registry_keys_and_trie_semantics():
+    for key in ("model.ResNet", "model.CNN", "data_loader.AudioDataLoader", "metric.Acc", "metric.PerClassAcc",
+                "loss_fn.ce_loss", "loss_fn.nll_loss", "dataset.SyntheticKWSDataset"):
+        assert find_cls(key) is not None, key
+    assert find_cls("model.Nope") is None and find_cls("model.Nope", 7) == 7
+    t = Trie()
+    t.add("a.b", 1)
+    t.add("a.b.c", 2)
+    assert (t.get("a.b"), t.get("a.b.c"), t.get("a.x", "d"), t.get("a")) == (1, 2, "d", None)
+    assert t.count == 2 - 3            # reference quirk: every successful walk decrements (utils/trie.py:31)
+
+    @register_cls("model.Tmp")
+    class Tmp:
+        pass
+    assert find_cls("model.Tmp") is Tmp
+
+
+def test_install_into_foreign_registry():
+    seen = {}
+
+    def foreign_register(key):
+        def deco(obj):
+            seen[key] = obj
+            return obj
+        return deco
+    honk2_amd.install_into(foreign_register)
+    assert seen["model.ResNet"] is find_cls("model.ResNet") and "data_loader.AudioDataLoader" in seen
+
+
+def test_size_calculators_match_conv_arithmetic():
+    assert calculate_conv_output_size([101, 40], (20, 8), stride=(1, 1)) == [82, 33]
+    assert calculate_pool_output_size([82, 33], (2, 2)) == [41, 16]
+    assert calculate_conv_output_size([101, 40], (16, 8), stride=(8, 1)) == [11, 33]
+    assert calculate_conv_output_size([25, 13], (3, 3), padding=1) == [25, 13]
+    assert calculate_conv_output_size([101, 40], (3, 3), padding=16, dilation=16) == [101, 40]
+    assert calculate_pool_output_size([101, 40], (4, 3)) == [25, 13]
+
+
+@pytest.mark.parametrize("fname", golden_model_files())
+def test_models_build_with_reference_state_dict_layout(fname):
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    model = find_cls(f"model.{name}")(dict(cfg))
+    assert model.num_params() == int(z["num_params"]) == model.num_trainable_params()
+    own = model.state_dict()
+    assert list(own.keys()) == list(sd.keys())
+    for k, v in sd.items():
+        assert tuple(own[k].shape) == tuple(np.shape(v)), k
+    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    model.eval()
+    with pytest.raises(RuntimeError):          # no GPU here and no CPU fallback, by design
+        model(torch.from_numpy(feats))
+
+
+def test_default_init_follows_torch_layer_init():
+    torch.manual_seed(0)
+    m = find_cls("model.ResNet")({"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 12})
+    torch.manual_seed(0)
+    ref = [torch.nn.Conv2d(1, 45, 3, padding=1, bias=False)]
+    for _ in range(6):
+        ref.append(torch.nn.Conv2d(45, 45, 3, padding=1, bias=False))
+        torch.nn.BatchNorm2d(45, affine=False)
+    lin = torch.nn.Linear(45, 12)
+    for i, conv in enumerate(ref):
+        assert torch.equal(m.layers[f"conv_{i}"].weight, conv.weight)
+    assert torch.equal(m.layers["output"].weight, lin.weight) and torch.equal(m.layers["output"].bias, lin.bias)
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol(lib_built):
+    header = open(os.path.join(ROOT, "include", "kws.h")).read()
+    declared = set(re.findall(r"\b(kws_[a-z_0-9]+)\s*\(", header))
+    declared -= {"kws_handle", "kws_model_desc", "kws_conv_desc"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib_built, sym), sym
+    assert lib_built.kws_abi_version() == 1
+    assert ctypes.sizeof(_lib.ModelDesc) == 4 * (11 + 1 + 10 + 4 + 3 + 4) + 8
+    # without a GPU kws_create must fail loudly, not fall back
+    if not torch.cuda.is_available():
+        h = ctypes.c_void_p()
+        d = _lib.make_desc(_lib.KWS_MODEL_NONE)
+        rc = lib_built.kws_create(ctypes.byref(d), ctypes.byref(h))
+        assert rc != 0 and b"no CPU fallback" in lib_built.kws_last_error()
+        with pytest.raises(RuntimeError):
+            _lib.Engine(d)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "honk2_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_data_loader_collate_and_config_defaults():
+    from honk2_amd.dataset import DatasetType, SyntheticKWSDataset
+    from honk2_amd.run.run_utils import init_data_loader, merge_configs
+    cfg = json.load(open(os.path.join(ROOT, "tests", "configs", "res8_synthetic.json")))
+    loader = init_data_loader(cfg, DatasetType.TEST)      # reference configs lack shuffle/num_workers: defaults apply
+    assert loader.batch_size == 32 and isinstance(loader.dataset, SyntheticKWSDataset)
+    assert len(loader.dataset.label_mapping) == 12 and loader.dataset.label_mapping[11] == "__silence__"
+    wav, target = loader.collate_fn([loader.dataset[i] for i in range(5)])
+    assert wav.shape == (5, 16000) and wav.dtype == torch.float32 and target.dtype == torch.int64
+    sil = [i for i in range(len(loader.dataset)) if loader.dataset.labels[i] == 11][0]
+    assert not loader.dataset[sil][0].any()               # silence class = exact zeros (dataset/gsc_dataset.py:165-166)
+    ragged = loader.collate_fn([(np.ones(10, np.float32), 1), (np.ones(7, np.float32), 2)])[0]
+    assert ragged.shape == (2, 10) and ragged[1, 7:].sum() == 0
+    base = {"a": {"x": 1}, "b": 2}
+    merged = merge_configs(base, {"a": {"y": 3}})
+    assert merged == {"a": {"y": 3}, "b": 2} and base["a"] == {"x": 1}      # shallow override, base untouched
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            next(iter(loader))
+
+
+def test_metrics_and_collect_follow_reference_semantics():
+    from honk2_amd.metric import Acc, PerClassAcc, collect_metrics
+    out = torch.tensor([[0.1, 0.9, 0.0], [0.8, 0.1, 0.1], [0.2, 0.2, 0.6], [0.5, 0.5, 0.0]])
+    tgt = torch.tensor([1, 0, 1, 0])
+    a, p = Acc(), PerClassAcc()
+    assert a.accumulate(out, tgt) == 0.75               # tie at row 3 -> first index, as torch.argmax
+    assert p.accumulate(out, tgt) == {1: 0.5, 0: 1.0}
+    res = collect_metrics({"Acc": a, "PerClassAcc": p}, {0: "zero", 1: "one", 2: "two"})
+    assert res == {"metric_Acc": 0.75, "metric_PerClassAcc": {"one": 0.5, "zero": 1.0}}
+    a.reset_metric(); p.reset_metric()
+    assert a.total == 0 and p.total == {}
+
+
+def test_checkpoint_loader_strips_dataparallel_prefix(tmp_path):
+    from honk2_amd.utils import load_checkpoint_state
+    path = tmp_path / "best_model.pt"
+    torch.save({"model_state_dict": {"module.layers.output.bias": torch.ones(3)}, "best_epoch": 4}, path)
+    sd, extra = load_checkpoint_state(str(path))
+    assert list(sd) == ["layers.output.bias"] and extra["best_epoch"] == 4
