@@ -60,7 +60,8 @@ def cpu_baseline(torch, wav_sample, sd, budget_s=12.0):
     """Time the CPU oracle on host cores over a bounded sample (about 10-20 s of CPU work)."""
     import numpy as np
     from oracle import frontend, models
-    threads = os.cpu_count() or 1
+    # the one-GPU box exposes every host core but grants a 16-worker share; stay inside the affinity mask and that share
+    threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(threads)
     x = wav_sample.cpu().numpy()
 
