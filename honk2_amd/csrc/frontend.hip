@@ -38,6 +38,12 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(FrontendParams p) {
     const int nfr = min(FE_FRAMES, p.T - t0);
     const int n = p.n_samples;
 
+    // The two workgroups resident on a CU start together and would stay in lockstep (staging and mel phases of
+    // one never under the MFMA phase of the other); delay the odd threadgroup slot (HW_REG_HW_ID[19:16]) of the
+    // first dispatch wave by about half a workgroup's lifetime.  Later workgroups inherit the offset.  Speed only.
+    if (blockIdx.x < 512 && (__builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11)) & 1) != 0)
+        for (int i = 0; i < p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+
     // ---- stage the reflect-padded samples this chunk needs: padded index i = 160*t0 + li
     {
         const float* src = p.wav + (size_t)clip * n;

@@ -437,8 +437,14 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
             h->last_plan = "res8_fused";
             Res8Params p{feat, logits, h->r8_w0.as<float>(), h->r8_apk.as<f32x4>(), h->r8_mean.as<float>(),
                          h->r8_rstd.as<float>(), h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq,
-                         h->d.n_labels};
-            const int grid = std::min(B, 512);
+                         h->d.n_labels, 0, 0};
+            static const int dbg = std::getenv("KWS_R8_DEBUG") ? std::atoi(std::getenv("KWS_R8_DEBUG")) : 0;
+            static const int grid_env = std::getenv("KWS_R8_GRID") ? std::atoi(std::getenv("KWS_R8_GRID")) : 512;
+            p.debug = dbg;
+            const int grid = std::min(B, grid_env);
+            // stagger only pays when each workgroup loops over several clips
+            static const int sleeps_env = std::getenv("KWS_STAGGER") ? std::atoi(std::getenv("KWS_STAGGER")) : 30;
+            p.stagger_sleeps = (B >= 4 * 512) ? sleeps_env : 0;
             HIP_TRY(launch_res8(p, grid, s));
         } else {
             h->last_plan = "layerwise";
@@ -604,7 +610,9 @@ int kws_mfcc(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_f
     int rc;
     if ((rc = prof_mark(h, h->ev_front, s))) return rc;
     FrontendParams p{d_wav, d_feat, h->dft.as<f32x4>(), h->melw.as<float>(), h->mel_lo.as<int>(), h->mel_hi.as<int>(),
-                     B, n_samples, T, h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES};
+                     B, n_samples, T, h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, 0};
+    static const int fe_sleeps = std::getenv("KWS_FE_STAGGER") ? std::atoi(std::getenv("KWS_FE_STAGGER")) : 12;
+    p.stagger_sleeps = (B * p.chunks >= 4 * 512) ? fe_sleeps : 0;
     HIP_TRY(launch_frontend(p, s));
     return prof_mark(h, h->ev_front, s);
 }

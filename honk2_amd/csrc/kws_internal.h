@@ -31,6 +31,7 @@ struct FrontendParams {
     const int* mel_lo;    // first / one-past-last non-zero bin per mel band
     const int* mel_hi;
     int B, n_samples, T, n_mels, chunks;
+    int stagger_sleeps;   // x ~3.4 us, first dispatch wave only (speed only)
 };
 size_t frontend_lds_bytes(int T);
 hipError_t launch_frontend(const FrontendParams& p, hipStream_t s);
@@ -47,13 +48,16 @@ constexpr size_t R8_APK_FLOATS = (size_t)R8_LAYERS * R8_GROUPS * 3 * 64 * 4;
 struct Res8Params {
     const float* feat;    // (B, 101, 40)
     float* logits;        // (B, n_labels)
-    const float* w0;      // conv_0 weight (45, 9)
+    const float* w0;      // conv_0 weight as channel pairs [24][9][2] (channels padded to 48 with zeros)
     const f32x4* apk;     // packed conv_1..6 weights
     const float* bn_mean; // (6, 48)
     const float* bn_rstd; // (6, 48)
     const float* out_w;   // (n_labels, 45)
     const float* out_b;   // (n_labels)
     int B, T, F, n_labels;
+    int stagger_sleeps;   // x ~3.4 us: one-time delay of the odd threadgroup slot of each CU (speed only)
+    int debug;            // KWS_R8_DEBUG bits, timing experiments only (results are wrong when set): 1 skip conv_0,
+                          // 2 skip the MFMA loop, 4 one workgroup per CU
 };
 size_t res8_lds_bytes();
 hipError_t launch_res8(const Res8Params& p, int grid, hipStream_t s);

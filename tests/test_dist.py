@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the N > 1 path -- contiguous clip sharding + rank-ordered all-gather of logits +
+counter reduction -- exercised with the same helpers bench.py and run/test.py use on RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from honk2_amd import dist_utils
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 64, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [dist_utils.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert dist_utils.shard_bounds(65536, 3, 8) == (24576, 32768)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w = dist_utils.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    from honk2_amd.metric import Acc, PerClassAcc
+    from honk2_amd.run.test import reduce_results
+    # every rank derives the same global "logits" and keeps its contiguous shard, like bench.py / run.test.main
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(total, 12, generator=g)
+    target = torch.randint(0, 12, (total,), generator=g)
+    lo, hi = dist_utils.shard_bounds(total, rank, world)
+    counts = [b - a for a, b in (dist_utils.shard_bounds(total, i, world) for i in range(world))]
+    gathered = dist_utils.all_gather_rows(logits[lo:hi].clone(), counts if len(set(counts)) > 1 else None)
+    assert torch.equal(gathered, logits)                       # rank order == clip order
+    acc, pca = Acc(), PerClassAcc()
+    acc.accumulate(logits[lo:hi], target[lo:hi])
+    pca.accumulate(logits[lo:hi], target[lo:hi])
+    res = reduce_results({"loss": float(rank)}, {"Acc": acc, "PerClassAcc": pca},
+                         {i: f"c{i}" for i in range(12)}, torch.device("cpu"))
+    ref_a, ref_p = Acc(), PerClassAcc()
+    ref_a.accumulate(logits, target)
+    ref_p.accumulate(logits, target)
+    assert res["metric_Acc"] == ref_a.get_metric()
+    assert res["metric_PerClassAcc"] == {f"c{k}": v for k, v in ref_p.get_metric().items()}
+    assert abs(res["loss"] - (world - 1) / 2) < 1e-12          # mean over ranks
+    np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.ones(1))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [64, 37])
+def test_two_rank_gather_and_reduce(tmp_path, total):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0.npy") and os.path.exists(tmp_path / "ok1.npy")

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Reduce rocprofv3 CSV output (kernel stats + PMC counter collections) to the kws_* kernels and print/save a
+compact per-kernel summary.  Usage: tools/summarize_prof.py <gpurun_out dir> <tag> -> profiles/r01/<tag>_*.csv|json"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main(src, tag, dst="profiles/r01"):
+    os.makedirs(dst, exist_ok=True)
+    summary = {}
+    for path in glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(path)) if r["Name"].startswith("kws::") or "nccl" in r["Name"].lower()]
+        with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+        for r in rows:
+            summary.setdefault(r["Name"].split("(")[0], {})["avg_ms"] = float(r["AverageNs"]) / 1e6
+            summary[r["Name"].split("(")[0]]["calls"] = int(r["Calls"])
+    for path in glob.glob(os.path.join(src, "**", "*_counter_collection.csv"), recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        meta = {}
+        for r in csv.DictReader(open(path)):
+            if not r["Kernel_Name"].startswith("kws::"):
+                continue
+            k = r["Kernel_Name"].split("(")[0]
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = {"vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
+                       "lds": int(r["LDS_Block_Size"]), "scratch": int(r["Scratch_Size"]), "grid": int(r["Grid_Size"])}
+        for k, d in agg.items():
+            s = summary.setdefault(k, {})
+            s.update(meta[k])
+            for c, v in d.items():
+                s[c] = sum(v) / len(v)
+    with open(os.path.join(dst, f"{tag}_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1, sort_keys=True)
+    print(json.dumps(summary, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
