@@ -73,7 +73,8 @@ struct kws_handle {
     bool force_layerwise = false;
 
     // front end
-    DevMem dft, melw, mel_lo, mel_hi;
+    DevMem dft, hann, melw, mel_lo, mel_hi;
+    int mel_maxw = 0;
 
     // parameters
     std::set<std::string> required, loaded;
@@ -152,11 +153,13 @@ int setup_frontend(kws_handle* h) {
             }
         }
         if (hi[i] <= lo[i]) lo[i] = hi[i] = 0;
+        h->mel_maxw = std::max(h->mel_maxw, hi[i] - lo[i]);
     }
-    std::vector<float> tab;
-    build_dft_table(tab);
+    std::vector<float> tab, hann;
+    build_dft_table(tab, hann);
     int rc;
     if ((rc = h->dft.upload(tab.data(), tab.size() * sizeof(float)))) return rc;
+    if ((rc = h->hann.upload(hann.data(), hann.size() * sizeof(float)))) return rc;
     if ((rc = h->melw.upload(wts.data(), wts.size() * sizeof(float)))) return rc;
     if ((rc = h->mel_lo.upload(lo.data(), lo.size() * sizeof(int)))) return rc;
     if ((rc = h->mel_hi.upload(hi.data(), hi.size() * sizeof(int)))) return rc;
@@ -609,10 +612,8 @@ int kws_mfcc(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_f
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
     if ((rc = prof_mark(h, h->ev_front, s))) return rc;
-    FrontendParams p{d_wav, d_feat, h->dft.as<f32x4>(), h->melw.as<float>(), h->mel_lo.as<int>(), h->mel_hi.as<int>(),
-                     B, n_samples, T, h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, 0};
-    static const int fe_sleeps = std::getenv("KWS_FE_STAGGER") ? std::atoi(std::getenv("KWS_FE_STAGGER")) : 12;
-    p.stagger_sleeps = (B * p.chunks >= 4 * 512) ? fe_sleeps : 0;
+    FrontendParams p{d_wav, d_feat, h->dft.as<f32x4>(), h->hann.as<float>(), h->melw.as<float>(), h->mel_lo.as<int>(),
+                     h->mel_hi.as<int>(), B, n_samples, T, h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, h->mel_maxw};
     HIP_TRY(launch_frontend(p, s));
     return prof_mark(h, h->ev_front, s);
 }

@@ -16,26 +16,28 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------- front end (frontend.hip)
 constexpr int FE_NFFT = 480;
 constexpr int FE_HOP = 160;
-constexpr int FE_ROWS = 128;        // DFT bins 0..127 computed per workgroup (4 waves x 32 rows)
+constexpr int FE_ROWS = 128;        // DFT bins 0..127 (four GEMMs of 64 rows: {Re, Im} x {even, odd} bins)
 constexpr int FE_NT = 7;            // 16-frame column tiles per workgroup chunk
 constexpr int FE_FRAMES = FE_NT * 16;
-constexpr int FE_S4 = 15;           // 60 k-steps of 4 folded sample pairs, packed 4 steps per float4
+constexpr int FE_STEPS = 30;        // k-steps of 4 columns: the twice-folded DFT has K = 120
+constexpr int FE_GROUPS = 8;        // k-steps packed 4 per float4 (last group half used)
 constexpr int FE_PSTRIDE = 116;     // row stride (words) of the power tile in LDS
-constexpr size_t FE_TABLE_FLOATS = (size_t)4 * FE_S4 * 4 * 64 * 4;
+constexpr size_t FE_TABLE_FLOATS = (size_t)4 * FE_GROUPS * 4 * 64 * 4;
 
 struct FrontendParams {
     const float* wav;     // (B, n_samples)
     float* feat;          // (B, T, n_mels)
-    const f32x4* dft;     // packed windowed cos/sin table, FE_TABLE_FLOATS floats
+    const f32x4* dft;     // packed cos/sin table, FE_TABLE_FLOATS floats
+    const float* hann;    // (FE_STEPS*4, 2): h[j], h[240-j]
     const float* melw;    // (n_mels, FE_ROWS) dense mel weights over bins 0..127
     const int* mel_lo;    // first / one-past-last non-zero bin per mel band
     const int* mel_hi;
     int B, n_samples, T, n_mels, chunks;
-    int stagger_sleeps;   // x ~3.4 us, first dispatch wave only (speed only)
+    int mel_maxw;         // widest mel filter in bins (fast path keeps <= 16 weights in registers)
 };
 size_t frontend_lds_bytes(int T);
 hipError_t launch_frontend(const FrontendParams& p, hipStream_t s);
-void build_dft_table(std::vector<float>& out);  // host side, double precision trig
+void build_dft_table(std::vector<float>& dft, std::vector<float>& hann);  // host side, double precision trig
 
 // ---------------------------------------------------------------- fused res8 (res8_fused.hip)
 constexpr int R8_C = 45, R8_H = 25, W8_W = 13, R8_NPOS = 325;
