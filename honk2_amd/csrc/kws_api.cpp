@@ -85,7 +85,7 @@ struct kws_handle {
     DevMem bn_scale, bn_shift, bn_mean, bn_rstd;   // (n_layers, C) each, layer-wise path
     DevMem out_w, out_b;
     // fused res8
-    DevMem r8_w0, r8_apk, r8_mean, r8_rstd;
+    DevMem r8_w0a, r8_apk, r8_bn, r8_zcells;
     std::vector<float> r8_apk_host;
     // CNN
     std::vector<ConvLayer> cconv;          // conv_0 [, conv_1]
@@ -294,15 +294,17 @@ int finalize(kws_handle* h) {
         if ((rc = h->bn_mean.upload(mu.data(), mu.size() * 4))) return rc;
         if ((rc = h->bn_rstd.upload(rs.data(), rs.size() * 4))) return rc;
         if (h->res8_eligible) {
-            std::vector<float> m48((size_t)R8_LAYERS * 48, 0.f), r48((size_t)R8_LAYERS * 48, 0.f);
+            std::vector<float> tab((size_t)R8_LAYERS * 96, 0.f);
             for (int i = 0; i < R8_LAYERS; ++i)
                 for (int c = 0; c < R8_C; ++c) {
-                    m48[(size_t)i * 48 + c] = mu[(size_t)i * C + c];
-                    r48[(size_t)i * 48 + c] = rs[(size_t)i * C + c];
+                    tab[(size_t)i * 96 + c] = sc[(size_t)i * C + c];
+                    tab[(size_t)i * 96 + 48 + c] = sf[(size_t)i * C + c];
                 }
-            if ((rc = h->r8_mean.upload(m48.data(), m48.size() * 4))) return rc;
-            if ((rc = h->r8_rstd.upload(r48.data(), r48.size() * 4))) return rc;
+            if ((rc = h->r8_bn.upload(tab.data(), tab.size() * 4))) return rc;
             if ((rc = h->r8_apk.upload(h->r8_apk_host.data(), h->r8_apk_host.size() * 4))) return rc;
+            std::vector<int> zc(1024);
+            build_res8_zero_cells(zc.data());
+            if ((rc = h->r8_zcells.upload(zc.data(), zc.size() * sizeof(int)))) return rc;
         }
     }
     h->dirty = false;
@@ -438,16 +440,13 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
     if (h->plan == PLAN_RESNET) {
         if (use_fused(h, T)) {
             h->last_plan = "res8_fused";
-            Res8Params p{feat, logits, h->r8_w0.as<float>(), h->r8_apk.as<f32x4>(), h->r8_mean.as<float>(),
-                         h->r8_rstd.as<float>(), h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq,
-                         h->d.n_labels, 0, 0};
+            Res8Params p{feat, logits, h->r8_w0a.as<float>(), h->r8_apk.as<f32x4>(), h->r8_bn.as<float>(),
+                         h->r8_zcells.as<int>(), h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq,
+                         h->d.n_labels, 0};
             static const int dbg = std::getenv("KWS_R8_DEBUG") ? std::atoi(std::getenv("KWS_R8_DEBUG")) : 0;
             static const int grid_env = std::getenv("KWS_R8_GRID") ? std::atoi(std::getenv("KWS_R8_GRID")) : 512;
             p.debug = dbg;
             const int grid = std::min(B, grid_env);
-            // stagger only pays when each workgroup loops over several clips
-            static const int sleeps_env = std::getenv("KWS_STAGGER") ? std::atoi(std::getenv("KWS_STAGGER")) : 30;
-            p.stagger_sleeps = (B >= 4 * 512) ? sleeps_env : 0;
             HIP_TRY(launch_res8(p, grid, s));
         } else {
             h->last_plan = "layerwise";
@@ -543,10 +542,9 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
             if ((rc = upload_packed(h->rconv[idx], src))) return rc;
             if (h->res8_eligible) {
                 if (idx == 0) {
-                    std::vector<float> pairs(24 * 9 * 2, 0.f);   // [pair][tap][2], channels padded to 48
-                    for (int c = 0; c < R8_C; ++c)
-                        for (int t = 0; t < 9; ++t) pairs[((size_t)(c / 2) * 9 + t) * 2 + (c & 1)] = src[c * 9 + t];
-                    if ((rc = h->r8_w0.upload(pairs.data(), pairs.size() * 4))) return rc;
+                    std::vector<float> frag(3 * 3 * 64);
+                    pack_res8_conv0(src, frag.data());
+                    if ((rc = h->r8_w0a.upload(frag.data(), frag.size() * 4))) return rc;
                 } else {
                     pack_res8_layer(src, h->r8_apk_host.data() + (size_t)(idx - 1) * R8_GROUPS * 3 * 64 * 4);
                 }

@@ -50,20 +50,21 @@ constexpr size_t R8_APK_FLOATS = (size_t)R8_LAYERS * R8_GROUPS * 3 * 64 * 4;
 struct Res8Params {
     const float* feat;    // (B, 101, 40)
     float* logits;        // (B, n_labels)
-    const float* w0;      // conv_0 weight as channel pairs [24][9][2] (channels padded to 48 with zeros)
+    const float* w0a;     // conv_0 weight as A fragments [3 channel tiles][3 k-steps][64 lanes]
     const f32x4* apk;     // packed conv_1..6 weights
-    const float* bn_mean; // (6, 48)
-    const float* bn_rstd; // (6, 48)
+    const float* bn_tab;  // (6, 96): per layer scale[48] = rstd, shift[48] = -mean*rstd (channels padded with 0)
+    const int* zcells;    // 1024 LDS cells to re-zero after the feature staging (build_res8_zero_cells)
     const float* out_w;   // (n_labels, 45)
     const float* out_b;   // (n_labels)
     int B, T, F, n_labels;
-    int stagger_sleeps;   // x ~3.4 us: one-time delay of the odd threadgroup slot of each CU (speed only)
     int debug;            // KWS_R8_DEBUG bits, timing experiments only (results are wrong when set): 1 skip conv_0,
                           // 2 skip the MFMA loop, 4 one workgroup per CU
 };
 size_t res8_lds_bytes();
 hipError_t launch_res8(const Res8Params& p, int grid, hipStream_t s);
 void pack_res8_layer(const float* w /*45x45x3x3*/, float* dst /*R8_GROUPS*3*64*4*/);
+void pack_res8_conv0(const float* w /*45x9*/, float* dst /*3*3*64*/);
+void build_res8_zero_cells(int* dst /*1024*/);
 
 // ---------------------------------------------------------------- layer-wise kernels (layerwise.hip)
 struct ConvGeom {
