@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Throughput of every shipped model config through the C ABI (features -> logits and wav -> logits) on one GPU.
+Not the headline benchmark (that is bench.py); used to fill the per-model table in DESIGN.md."""
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from honk2_amd.utils import find_cls
+from oracle import weights
+
+MFLOP = {"resnet__res8": 74.35, "resnet__res8_narrow": 14.05, "resnet__res15": 1917.63, "resnet__res15_narrow": 342.66,
+         "resnet__res26": 878.07, "resnet__res26_narrow": 157.33, "cnn__cnn-trad-pool2": 192.37,
+         "cnn__cnn-trad-fpool3": 249.19, "cnn__cnn-one-fpool3": 66.57, "cnn__cnn-one-fstride4": 62.54,
+         "cnn__cnn-one-fstride8": 61.76, "cnn__cnn-tstride2": 152.43, "cnn__cnn-tstride4": 64.28,
+         "cnn__cnn-tstride8": 34.05, "cnn__cnn-tpool2": 204.91, "cnn__cnn-tpool3": 147.40}
+
+
+def main():
+    only = sys.argv[1:] or None
+    dev = torch.device("cuda:0")
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "model_*.npz"))):
+        tag = os.path.basename(path)[6:-4]
+        if tag.startswith("hey_snips") or (only and tag not in only):
+            continue
+        z = np.load(path)
+        name, cfg = str(z["model_name"]), json.loads(str(z["model_config"]))
+        sd = weights.make_state_dict(name, cfg, seed=7)
+        model = find_cls(f"model.{name}")(dict(cfg))
+        model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
+        model = model.to(dev).eval()
+        batch = 8192 if MFLOP[tag] < 400 else 2048
+        x = torch.randn(batch, 101, 40, device=dev) * 2.5 + 0.65
+        model(x[:64])
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        cps = batch / dt
+        print(json.dumps({"model": tag, "plan": model.plan_name(), "batch": batch, "ms": round(dt * 1e3, 2),
+                          "clips_per_s": round(cps), "TFLOPs_alg": round(cps * MFLOP[tag] * 1e6 / 1e12, 2),
+                          "frac_fp32_peak": round(cps * MFLOP[tag] * 1e6 / 157.3e12, 3)}), flush=True)
+        del model
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
