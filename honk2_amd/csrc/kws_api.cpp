@@ -55,8 +55,9 @@ enum Plan { PLAN_FRONTEND_ONLY, PLAN_RESNET, PLAN_CNN };
 
 struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the layer-wise plans
     ConvGeom g{};           // B/H/W/Ho/Wo filled per call for ResNet, at create for CNN
-    DevMem apk, bias;
-    bool has_bias = false;
+    DevMem apk, bias, border;
+    bool has_bias = false, has_border = false;
+    std::vector<float> w_host;   // ResNet: raw weights kept until finalize() folds the previous BatchNorm in
 };
 
 struct BnHost {
@@ -82,7 +83,7 @@ struct kws_handle {
     // ResNet
     std::vector<ConvLayer> rconv;          // conv_0 .. conv_n  (layer-wise packing)
     std::vector<BnHost> bn;                // bn_1 .. bn_n (index i-1)
-    DevMem bn_scale, bn_shift, bn_mean, bn_rstd;   // (n_layers, C) each, layer-wise path
+    DevMem bn_mean, bn_rstd;               // (n_layers, C) each: the LAST layer's BN is applied after the spatial mean
     DevMem out_w, out_b;
     // fused res8
     DevMem r8_w0a, r8_apk, r8_bn, r8_zcells;
@@ -289,10 +290,43 @@ int finalize(kws_handle* h) {
                 sf[(size_t)i * C + c] = (float)(-(double)h->bn[i].mean[c] * r);
             }
         int rc;
-        if ((rc = h->bn_scale.upload(sc.data(), sc.size() * 4))) return rc;
-        if ((rc = h->bn_shift.upload(sf.data(), sf.size() * 4))) return rc;
         if ((rc = h->bn_mean.upload(mu.data(), mu.size() * 4))) return rc;
         if ((rc = h->bn_rstd.upload(rs.data(), rs.size() * 4))) return rc;
+        // layer-wise plan: conv_i (i >= 2) reads BN_{i-1}(x).  Fold the BN scale into the weights and turn the BN
+        // shift into a border bias: for each of the 16 border classes (top/bottom/left/right tap rows in bounds) the sum
+        // over in-bounds taps of sum_ci W[co][ci][tap] * shift[ci]  (zero padding is applied AFTER BN in the reference).
+        for (int i = 0; i <= n; ++i) {
+            ConvLayer& L = h->rconv[i];
+            std::vector<float> wf = L.w_host;
+            if (i >= 2) {
+                const float* scp = sc.data() + (size_t)(i - 2) * C;
+                const float* sfp = sf.data() + (size_t)(i - 2) * C;
+                std::vector<float> border((size_t)16 * C, 0.f);
+                for (int co = 0; co < C; ++co) {
+                    double tapsum[9];
+                    for (int t9 = 0; t9 < 9; ++t9) {
+                        double acc = 0.0;
+                        for (int ci = 0; ci < C; ++ci) acc += (double)L.w_host[((size_t)co * C + ci) * 9 + t9] * sfp[ci];
+                        tapsum[t9] = acc;
+                    }
+                    for (int mask = 0; mask < 16; ++mask) {
+                        double acc = 0.0;
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const bool rowok = ky == 1 || (ky == 0 ? (mask & 1) : (mask & 2));
+                                const bool colok = kx == 1 || (kx == 0 ? (mask & 4) : (mask & 8));
+                                if (rowok && colok) acc += tapsum[ky * 3 + kx];
+                            }
+                        border[(size_t)mask * C + co] = (float)acc;
+                    }
+                    for (int ci = 0; ci < C; ++ci)
+                        for (int t9 = 0; t9 < 9; ++t9) wf[((size_t)co * C + ci) * 9 + t9] *= scp[ci];
+                }
+                if ((rc = L.border.upload(border.data(), border.size() * 4))) return rc;
+                L.has_border = true;
+            }
+            if ((rc = upload_packed(L, wf.data()))) return rc;
+        }
         if (h->res8_eligible) {
             std::vector<float> tab((size_t)R8_LAYERS * 96, 0.f);
             for (int i = 0; i < R8_LAYERS; ++i)
@@ -379,7 +413,7 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
         // conv_0 + ReLU (+ AvgPool)
         ConvGeom g0 = h->rconv[0].g;
         set_spatial(g0, nb, sh.T, sh.F);
-        ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr};
+        ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr};
         HIP_TRY(launch_conv(g0, a0, s));
         if (sh.pooled) HIP_TRY(launch_pool(bufA, X, nb * C, sh.T, sh.F, d.pool_h, d.pool_w, 0, s));
         // conv_i: odd i writes Y from X, even i accumulates into X from Y (prev_x lives in X)
@@ -388,8 +422,7 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
             set_spatial(g, nb, sh.H, sh.W);
             const bool even = (i % 2) == 0;
             ConvArgs a{even ? Y : X, even ? X : Y, h->rconv[i].apk.as<float>(), nullptr,
-                       i > 1 ? h->bn_scale.as<float>() + (size_t)(i - 2) * C : nullptr,
-                       i > 1 ? h->bn_shift.as<float>() + (size_t)(i - 2) * C : nullptr};
+                       h->rconv[i].has_border ? h->rconv[i].border.as<float>() : nullptr};
             HIP_TRY(launch_conv(g, a, s));
         }
         const float* fin = (d.n_layers % 2 == 0) ? X : Y;
@@ -415,7 +448,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             ConvGeom g = h->cconv[i].g;
             g.B = nb;
             float* conv_out_buf = other(cur);
-            ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), h->cconv[i].bias.as<float>(), nullptr, nullptr};
+            ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), h->cconv[i].bias.as<float>(), nullptr};
             HIP_TRY(launch_conv(g, a, s));
             float* pooled = other(conv_out_buf);
             HIP_TRY(launch_pool(conv_out_buf, pooled, nb * g.Cout, g.Ho, g.Wo, d.pool_kh[i], d.pool_kw[i], 1, s));
@@ -426,7 +459,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             g.B = nb;
             const bool last = i + 1 == h->clin.size();
             float* dst = last ? logits + (size_t)b0 * d.n_labels : other(cur);
-            ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), h->clin[i].bias.as<float>(), nullptr, nullptr};
+            ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), h->clin[i].bias.as<float>(), nullptr};
             HIP_TRY(launch_conv(g, a, s));
             cur = dst;
         }
@@ -539,7 +572,7 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
         } else if (std::sscanf(name.c_str(), "layers.conv_%d.%31s", &idx, field) == 2) {
             const size_t n = idx == 0 ? (size_t)C * 9 : (size_t)C * C * 9;
             if ((rc = need(n))) return rc;
-            if ((rc = upload_packed(h->rconv[idx], src))) return rc;
+            h->rconv[idx].w_host.assign(src, src + n);
             if (h->res8_eligible) {
                 if (idx == 0) {
                     std::vector<float> frag(3 * 3 * 64);

@@ -82,10 +82,9 @@ struct ConvGeom {
 struct ConvArgs {
     const float* in;       // (B, Cin, H, W)
     float* out;            // (B, Cout, Ho, Wo)
-    const float* apk;      // packed weights [mgroup][kstep][MT][64]
+    const float* apk;      // packed weights [mgroup][kstep][MT][64] (previous layer's BN scale already folded in)
     const float* bias;     // (Cout) or nullptr
-    const float* in_scale; // BN-on-load: x*scale[c] + shift[c] for in-bounds taps; nullptr = identity
-    const float* in_shift;
+    const float* border;   // (16, Cout) or nullptr: previous layer's BN shift summed over the in-bounds taps, by border class
 };
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, hipStream_t s);
 void pack_conv_weights(const ConvGeom& g, const float* w /*Cout,Cin,kh,kw*/, std::vector<float>& dst);

@@ -6,30 +6,42 @@
 //   M = output channels (tiles of 16, MT tiles per wave), N = B*Ho*Wo output positions flattened over the batch
 //   (64 per wave, 256 per workgroup), K = taps x input channels.
 //   * K order (ky, kx, cin padded to 4) for Cin > 1: within a tap the four k-slots of an MFMA are four consecutive
-//     input channels, so tap geometry / bounds are computed once per tap and the inner loop is one predicated
-//     global load + (optional BatchNorm-on-load FMA) per B fragment.
-//   * K order (ky, kx padded to 4) for Cin == 1 (every conv_0, and every Linear, which is run as a 1 x K "conv"
-//     over the flattened feature vector): the four k-slots are four consecutive columns, i.e. contiguous memory.
-//   * BatchNorm of the PREVIOUS layer is applied on load (zero padding stays exactly zero, as in the reference
-//     where padding is applied after BN); ReLU, bias and the residual add are fused into the epilogue.  With
-//     `accumulate` the output buffer already holds prev_x and becomes the new prev_x, so a ResNet needs two
-//     activation buffers.
+//     input channels; (ky, kx padded to 4) for Cin == 1 (every conv_0, and every Linear, which is run as a 1 x K
+//     "conv" over the flattened feature vector): the four k-slots are four consecutive columns.
+//   * fp32 VALU instructions cost matrix-pipe time on gfx950 (see res8_fused.hip), so the inner loop has none:
+//     B fragments are buffer loads whose address is (per-tap lane register) + (scalar channel-group offset) and whose
+//     hardware range check returns 0 for padding taps (out-of-bounds lanes carry an offset past the buffer);
+//     A fragments are buffer loads at lane*4 + scalar step offset.  The next k-step's fragments are requested
+//     before the current step's MFMAs.
+//   * BatchNorm of the PREVIOUS layer never appears in the loop: its scale is folded into this layer's weights on
+//     the host, and its shift -- which must NOT be applied to zero-padding taps -- becomes a 16-entry "border bias"
+//     per output channel, indexed by which of the top / bottom / left / right tap rows are in bounds.
+//   * ReLU, bias, border bias and the residual add are fused into the epilogue.  With `accumulate` the output buffer
+//     already holds prev_x and becomes the new prev_x, so a ResNet needs two activation buffers.
 //   Activations are fp32 (B, C, H, W) in the caller-provided workspace.
 #include "kws_internal.h"
 
 namespace kws {
 
+namespace {
+constexpr int OOB = (int)0x80000000;   // byte offset beyond any activation buffer (they are <= 1 GiB)
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+}  // namespace
+
 template <int MT, bool KX>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = tid >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
     const int pcol = lane & 15;
     const int npc = gm.Ho * gm.Wo;
     const long long ntot = (long long)gm.B * npc;
     const long long n0 = ((long long)blockIdx.x * 4 + w) * 64;
     const int hw = gm.H * gm.W;
+    const bool padded = gm.ph > 0 || gm.pw > 0;
 
     bool valid[4];
     int iy0[4], ix0[4], inb[4], pos[4], bidx[4];
@@ -49,88 +61,114 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a
         inb[j] = b * gm.Cin * hw;
     }
 
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((size_t)gm.B * gm.Cin * hw * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.apk + (size_t)blockIdx.y * gm.ksteps * MT * 64), 0, gm.ksteps * MT * 256, 0x00020000);
+
+    // Outer index t ("tap"): the unit whose lane addresses / bounds are computed once (VALU); inner index: steps that
+    // only advance a SCALAR byte offset.  Unpadded Cin == 1 convs and Linears need no bounds at all, so their whole
+    // K range is one "tap" and the (ky, kx-group) walk is scalar arithmetic.
+    const bool flat = KX && !padded;
+    const int ntaps = KX ? (padded ? gm.kh * gm.inner_steps : 1) : gm.kh * gm.kw;
+    const int ncg = KX ? (padded ? 1 : gm.ksteps) : gm.inner_steps;
+    const int sstride = (KX ? 4 * gm.dw : 4 * hw) * 4;                       // bytes per inner step
+    const int rowjump = flat ? (gm.dh * gm.W - gm.inner_steps * 4 * gm.dw) * 4 : 0;   // extra bytes when kx wraps to the next ky
+
+    int voff[4];
+    auto tap_voff = [&](int t) {
+        if (KX) {
+            const int ky = padded ? t / gm.inner_steps : 0;
+            const int kxl = (padded ? 4 * (t - ky * gm.inner_steps) : 0) + g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = iy0[j] + ky * gm.dh;
+                const int ix = ix0[j] + kxl * gm.dw;
+                bool ok = valid[j];
+                if (padded) ok = ok && iy >= 0 && iy < gm.H && ix >= 0 && ix < gm.W && kxl < gm.kw;
+                voff[j] = ok ? (inb[j] + iy * gm.W + ix) * 4 : OOB;
+            }
+        } else {
+            const int ky = t / gm.kw;
+            const int kx = t - ky * gm.kw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = iy0[j] + ky * gm.dh;
+                const int ix = ix0[j] + kx * gm.dw;
+                const bool ok = valid[j] && iy >= 0 && iy < gm.H && ix >= 0 && ix < gm.W;
+                voff[j] = ok ? (inb[j] + iy * gm.W + ix + g * hw) * 4 : OOB;
+            }
+        }
+    };
+
     f32x4 acc[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* A = a.apk + (size_t)blockIdx.y * gm.ksteps * MT * 64 + lane;
-    const float* __restrict__ in = a.in;
+    const int avoff = lane * 4;
+    int sa = 0;   // scalar byte offset of the current k-step's A fragments (steps are consecutive across taps)
 
-    if (KX) {
-        for (int ky = 0; ky < gm.kh; ++ky) {
-            bool rowok[4];
-            int rowbase[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int iy = iy0[j] + ky * gm.dh;
-                rowok[j] = valid[j] && iy >= 0 && iy < gm.H;
-                rowbase[j] = inb[j] + iy * gm.W;
-            }
-            for (int xg = 0; xg < gm.inner_steps; ++xg) {
-                const int kx = 4 * xg + g;
-                const bool kok = kx < gm.kw;
-                float am[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) am[m] = A[m * 64];
-                A += MT * 64;
-                float bv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ix = ix0[j] + kx * gm.dw;
-                    const bool ok = rowok[j] && kok && ix >= 0 && ix < gm.W;
-                    const float v = in[ok ? rowbase[j] + ix : 0];
-                    bv[j] = ok ? v : 0.f;
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[m], bv[j], acc[m][j], 0, 0, 0);
-            }
-        }
-    } else {
-        const bool bn = a.in_scale != nullptr;
-        for (int ky = 0; ky < gm.kh; ++ky)
-            for (int kx = 0; kx < gm.kw; ++kx) {
-                bool ok[4];
-                int base[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int iy = iy0[j] + ky * gm.dh;
-                    const int ix = ix0[j] + kx * gm.dw;
-                    ok[j] = valid[j] && iy >= 0 && iy < gm.H && ix >= 0 && ix < gm.W;
-                    base[j] = ok[j] ? inb[j] + iy * gm.W + ix : 0;
-                }
-                for (int cg = 0; cg < gm.inner_steps; ++cg) {
-                    const int c = 4 * cg + g;
-                    const bool cok = c < gm.Cin;
-                    const int coff = cok ? c * hw : 0;
-                    float sc = 1.f, sf = 0.f;
-                    if (bn) {
-                        sc = a.in_scale[cok ? c : 0];
-                        sf = a.in_shift[cok ? c : 0];
-                    }
-                    float am[MT];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) am[m] = A[m * 64];
-                    A += MT * 64;
-                    float bv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool k = ok[j] && cok;
-                        const float v = in[k ? base[j] + coff : 0];
-                        bv[j] = k ? fmaf(v, sc, sf) : 0.f;
-                    }
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[m], bv[j], acc[m][j], 0, 0, 0);
-                }
-            }
+#define LW_LOAD(AR, BR)                                                                     \
+    {                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) BR[j] = bload(rin, voff[j], sb);      \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) AR[m] = bload(rwt, avoff + m * 256, sa); \
+        __builtin_amdgcn_sched_barrier(0); /* keep the prefetch ABOVE the MFMAs it overlaps */ \
     }
+#define LW_MFMA(AR, BR)                                                                     \
+    {                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                   \
+                acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AR[m], BR[j], acc[m][j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    }
+#define LW_ADVANCE()                                                                        \
+    {                                                                                       \
+        sb += sstride;                                                                      \
+        sa += MT * 256;                                                                     \
+        if (flat && ++xg == gm.inner_steps) {                                               \
+            xg = 0;                                                                         \
+            sb += rowjump;                                                                  \
+        }                                                                                   \
+    }
+
+    for (int t = 0; t < ntaps; ++t) {
+        tap_voff(t);
+        // Ping-pong pipeline over this tap's ncg steps: the loads of step i+1 are issued, straight-line, before the
+        // MFMAs of step i; the last one or two steps are peeled so every load in the loop is a real one.
+        int sb = 0, xg = 0, i = 0;
+        float a0[MT], b0[4], a1[MT], b1[4];
+        LW_LOAD(a0, b0)
+        while (i + 2 < ncg) {
+            LW_ADVANCE()
+            LW_LOAD(a1, b1)
+            LW_MFMA(a0, b0)
+            LW_ADVANCE()
+            LW_LOAD(a0, b0)
+            LW_MFMA(a1, b1)
+            i += 2;
+        }
+        if (i + 1 < ncg) {
+            LW_ADVANCE()
+            LW_LOAD(a1, b1)
+            LW_MFMA(a0, b0)
+            LW_MFMA(a1, b1)
+        } else {
+            LW_MFMA(a0, b0)
+        }
+        sa += MT * 256;   // first step of the next tap
+    }
+#undef LW_LOAD
+#undef LW_MFMA
+#undef LW_ADVANCE
+
+    // border class of each position (3x3 "same" convs only): bit0 top row of taps in bounds, bit1 bottom, bit2 left, bit3 right
+    int bmask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        bmask[j] = (iy0[j] >= 0 ? 1 : 0) | (iy0[j] + 2 * gm.dh < gm.H ? 2 : 0) | (ix0[j] >= 0 ? 4 : 0) |
+                   (ix0[j] + 2 * gm.dw < gm.W ? 8 : 0);
 
     // epilogue: D[row = 4g + r][col = pcol]; rows are output channels
 #pragma unroll
@@ -144,6 +182,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a
             for (int j = 0; j < 4; ++j) {
                 if (!valid[j]) continue;
                 float v = acc[m][j][r] + bias;
+                if (a.border) v += a.border[bmask[j] * gm.Cout + co];
                 if (gm.relu) v = fmaxf(v, 0.f);
                 const size_t idx = ((size_t)bidx[j] * gm.Cout + co) * npc + pos[j];
                 if (gm.accumulate) v += a.out[idx];
