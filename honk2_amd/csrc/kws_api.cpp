@@ -371,6 +371,24 @@ int chunk_clips(size_t per_clip_elems, int B) {
     return (int)std::min<size_t>(cb, (size_t)std::max(B, 1));
 }
 
+// Linears (flat Cin == 1 "convs") over a chunk of clips launch only B/256 workgroups; split K so the chip is filled.
+int plan_ksplit(const ConvGeom& g, int nb) {
+    if (!(g.kx_inner && g.ph == 0 && g.pw == 0)) return 1;
+    const long long wgs = (((long long)nb * g.Ho * g.Wo + 255) / 256) * ((g.mtiles + g.MT - 1) / g.MT);
+    if (wgs >= 256 || g.ksteps < 64) return 1;
+    int ks = (int)std::min<long long>((1024 + wgs - 1) / wgs, g.ksteps / 32);
+    return std::max(1, std::min(ks, 256));
+}
+
+size_t cnn_partial_bytes(const kws_handle* h, int cb) {
+    size_t mx = 0;
+    for (const auto& L : h->clin) {
+        const int ks = plan_ksplit(L.g, cb);
+        if (ks > 1) mx = std::max(mx, (size_t)ks * cb * L.g.Cout * L.g.Ho * L.g.Wo * 4);
+    }
+    return align256(mx);
+}
+
 size_t act_bytes(const kws_handle* h, int B, int T) {
     if (h->plan == PLAN_RESNET) {
         if (use_fused(h, T)) return 0;
@@ -381,7 +399,7 @@ size_t act_bytes(const kws_handle* h, int B, int T) {
     }
     if (h->plan == PLAN_CNN) {
         const int cb = chunk_clips(h->cnn_max_elems, B);
-        return 2 * align256(h->cnn_max_elems * cb * 4);
+        return 2 * align256(h->cnn_max_elems * cb * 4) + cnn_partial_bytes(h, cb);
     }
     return 0;
 }
@@ -413,7 +431,7 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
         // conv_0 + ReLU (+ AvgPool)
         ConvGeom g0 = h->rconv[0].g;
         set_spatial(g0, nb, sh.T, sh.F);
-        ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr};
+        ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr};
         HIP_TRY(launch_conv(g0, a0, s));
         if (sh.pooled) HIP_TRY(launch_pool(bufA, X, nb * C, sh.T, sh.F, d.pool_h, d.pool_w, 0, s));
         // conv_i: odd i writes Y from X, even i accumulates into X from Y (prev_x lives in X)
@@ -421,7 +439,7 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
             ConvGeom g = h->rconv[i].g;
             set_spatial(g, nb, sh.H, sh.W);
             const bool even = (i % 2) == 0;
-            ConvArgs a{even ? Y : X, even ? X : Y, h->rconv[i].apk.as<float>(), nullptr,
+            ConvArgs a{even ? Y : X, even ? X : Y, h->rconv[i].apk.as<float>(), nullptr, nullptr,
                        h->rconv[i].has_border ? h->rconv[i].border.as<float>() : nullptr};
             HIP_TRY(launch_conv(g, a, s));
         }
@@ -434,12 +452,34 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
     return KWS_OK;
 }
 
+int launch_conv_auto(ConvGeom g, ConvArgs a, int nb, float* partial, size_t partial_bytes, hipStream_t s) {
+    g.B = nb;
+    g.ksplit = plan_ksplit(g, nb);
+    if (g.ksplit > 1) {
+        g.ksteps_split = (g.ksteps + g.ksplit - 1) / g.ksplit;
+        g.ksplit = (g.ksteps + g.ksteps_split - 1) / g.ksteps_split;
+        const long long total = (long long)nb * g.Cout * g.Ho * g.Wo;
+        if (!partial || (size_t)g.ksplit * total * 4 > partial_bytes) g.ksplit = 1;   // no room: fall back to one pass
+        else {
+            a.partial = partial;
+            HIP_TRY(launch_conv(g, a, s));
+            HIP_TRY(launch_splitk_reduce(partial, a.out, a.bias, g.ksplit, total, g.Cout, g.Ho * g.Wo, g.relu, s));
+            return KWS_OK;
+        }
+    }
+    g.ksteps_split = g.ksteps;
+    HIP_TRY(launch_conv(g, a, s));
+    return KWS_OK;
+}
+
 int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
     const kws_model_desc& d = h->d;
     if (T != d.time) return fail(KWS_EINVAL, "CNN was built for a different number of frames (config[\"time\"])");
     const int cb = chunk_clips(h->cnn_max_elems, B);
     float* P = (float*)ws;
     float* Q = (float*)(ws + align256(h->cnn_max_elems * cb * 4));
+    float* part = (float*)(ws + 2 * align256(h->cnn_max_elems * cb * 4));
+    const size_t part_bytes = cnn_partial_bytes(h, cb);
     auto other = [&](const float* c) -> float* { return c == P ? Q : P; };
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
@@ -448,7 +488,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             ConvGeom g = h->cconv[i].g;
             g.B = nb;
             float* conv_out_buf = other(cur);
-            ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), h->cconv[i].bias.as<float>(), nullptr};
+            ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), h->cconv[i].bias.as<float>(), nullptr, nullptr};
             HIP_TRY(launch_conv(g, a, s));
             float* pooled = other(conv_out_buf);
             HIP_TRY(launch_pool(conv_out_buf, pooled, nb * g.Cout, g.Ho, g.Wo, d.pool_kh[i], d.pool_kw[i], 1, s));
@@ -459,8 +499,9 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             g.B = nb;
             const bool last = i + 1 == h->clin.size();
             float* dst = last ? logits + (size_t)b0 * d.n_labels : other(cur);
-            ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), h->clin[i].bias.as<float>(), nullptr};
-            HIP_TRY(launch_conv(g, a, s));
+            ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), h->clin[i].bias.as<float>(), nullptr, nullptr};
+            int rc = launch_conv_auto(g, a, nb, part, part_bytes, s);
+            if (rc) return rc;
             cur = dst;
         }
     }

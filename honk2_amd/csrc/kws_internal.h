@@ -78,17 +78,23 @@ struct ConvGeom {
     int mtiles;            // ceil(Cout/16)
     int MT;                // m-tiles per wave (1..4); grid.y = ceil(mtiles/MT)
     int relu, accumulate;  // epilogue: ReLU; out += value (residual kept in the output buffer)
+    int ksplit;            // > 1: K range split over blockIdx.z (flat Cin == 1 mode only); partial sums go to ConvArgs::partial
+    int ksteps_split;      // k-steps per split
 };
 struct ConvArgs {
     const float* in;       // (B, Cin, H, W)
     float* out;            // (B, Cout, Ho, Wo)
     const float* apk;      // packed weights [mgroup][kstep][MT][64] (previous layer's BN scale already folded in)
     const float* bias;     // (Cout) or nullptr
+    float* partial;        // (ksplit, B, Cout, Ho*Wo) raw partial sums when ksplit > 1 (then reduced by launch_splitk_reduce)
     const float* border;   // (16, Cout) or nullptr: previous layer's BN shift summed over the in-bounds taps, by border class
 };
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, hipStream_t s);
 void pack_conv_weights(const ConvGeom& g, const float* w /*Cout,Cin,kh,kw*/, std::vector<float>& dst);
 int choose_mt(int mtiles);
+// out[i] = (relu?)(bias[co] + sum_z partial[z][i]) for i over (B, Cout, npc)
+hipError_t launch_splitk_reduce(const float* partial, float* out, const float* bias, int ksplit, long long total,
+                                int Cout, int npc, int relu, hipStream_t s);
 
 hipError_t launch_pool(const float* in, float* out, int planes /*B*C*/, int H, int W, int kh, int kw, int is_max,
                        hipStream_t s);

@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a
     // K range is one "tap" and the (ky, kx-group) walk is scalar arithmetic.
     const bool flat = KX && !padded;
     const int ntaps = KX ? (padded ? gm.kh * gm.inner_steps : 1) : gm.kh * gm.kw;
-    const int ncg = KX ? (padded ? 1 : gm.ksteps) : gm.inner_steps;
+    // split-K (flat mode only): this workgroup covers k-steps [s_begin, s_begin + ncg)
+    const int s_begin = (flat && gm.ksplit > 1) ? (int)blockIdx.z * gm.ksteps_split : 0;
+    const int ncg = KX ? (padded ? 1 : min(gm.ksteps - s_begin, (gm.ksplit > 1 ? gm.ksteps_split : gm.ksteps)))
+                       : gm.inner_steps;
     const int sstride = (KX ? 4 * gm.dw : 4 * hw) * 4;                       // bytes per inner step
     const int rowjump = flat ? (gm.dh * gm.W - gm.inner_steps * 4 * gm.dw) * 4 : 0;   // extra bytes when kx wraps to the next ky
 
@@ -108,7 +111,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a
         for (int j = 0; j < 4; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int avoff = lane * 4;
-    int sa = 0;   // scalar byte offset of the current k-step's A fragments (steps are consecutive across taps)
+    int sa = s_begin * MT * 256;   // scalar byte offset of the current k-step's A fragments (steps are consecutive across taps)
+    const int ky_begin = flat ? s_begin / gm.inner_steps : 0;
+    const int xg_begin = flat ? s_begin - ky_begin * gm.inner_steps : 0;
 
 #define LW_LOAD(AR, BR)                                                                     \
     {                                                                                       \
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a
         tap_voff(t);
         // Ping-pong pipeline over this tap's ncg steps: the loads of step i+1 are issued, straight-line, before the
         // MFMAs of step i; the last one or two steps are peeled so every load in the loop is a real one.
-        int sb = 0, xg = 0, i = 0;
+        int sb = (ky_begin * gm.dh * gm.W + xg_begin * 4 * gm.dw) * 4, xg = xg_begin, i = 0;
         float a0[MT], b0[4], a1[MT], b1[4];
         LW_LOAD(a0, b0)
         while (i + 2 < ncg) {
@@ -181,6 +186,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!valid[j]) continue;
+                if (gm.ksplit > 1) {   // raw partial sum; bias / ReLU are applied by the reduce kernel
+                    a.partial[((size_t)blockIdx.z * gm.B + bidx[j]) * gm.Cout * npc + (size_t)co * npc + pos[j]] = acc[m][j][r];
+                    continue;
+                }
                 float v = acc[m][j][r] + bias;
                 if (a.border) v += a.border[bmask[j] * gm.Cout + co];
                 if (gm.relu) v = fmaxf(v, 0.f);
@@ -206,7 +215,7 @@ int choose_mt(int mtiles) {
 template <int MT>
 static hipError_t launch_conv_mt(const ConvGeom& g, const ConvArgs& a, hipStream_t s) {
     const long long ntot = (long long)g.B * g.Ho * g.Wo;
-    dim3 grid((unsigned)((ntot + 255) / 256), (unsigned)((g.mtiles + MT - 1) / MT));
+    dim3 grid((unsigned)((ntot + 255) / 256), (unsigned)((g.mtiles + MT - 1) / MT), (unsigned)(g.ksplit > 1 ? g.ksplit : 1));
     if (g.kx_inner)
         hipLaunchKernelGGL((conv_igemm_kernel<MT, true>), grid, dim3(256), 0, s, g, a);
     else
@@ -251,6 +260,25 @@ void pack_conv_weights(const ConvGeom& g, const float* w, std::vector<float>& ds
                         v = w[(((size_t)co * g.Cin + c) * g.kh + ky) * g.kw + kx];
                     dst[(((size_t)mg * g.ksteps + ks) * g.MT + m) * 64 + lane] = v;
                 }
+}
+
+// ------------------------------------------------------------------------------------------------ split-K reduce
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            const float* __restrict__ bias, int ksplit, long long total,
+                                                            int Cout, int npc, int relu) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float v = bias ? bias[(int)((i / npc) % Cout)] : 0.f;
+    for (int z = 0; z < ksplit; ++z) v += partial[(size_t)z * total + i];   // fixed order: deterministic
+    out[i] = relu ? fmaxf(v, 0.f) : v;
+}
+
+hipError_t launch_splitk_reduce(const float* partial, float* out, const float* bias, int ksplit, long long total,
+                                int Cout, int npc, int relu, hipStream_t s) {
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, out, bias,
+                       ksplit, total, Cout, npc, relu);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
