@@ -86,8 +86,10 @@ struct kws_handle {
     DevMem bn_mean, bn_rstd;               // (n_layers, C) each: the LAST layer's BN is applied after the spatial mean
     DevMem out_w, out_b;
     // fused res8
-    DevMem r8_w0a, r8_apk, r8_bn, r8_zcells;
+    DevMem r8_w0a, r8_apk, r8_bn, r8_zcells, r8x_apk;
     std::vector<float> r8_apk_host;
+    std::vector<unsigned short> r8x_apk_host;
+    bool res8_fp32_mfma = false;   // KWS_RES8_IMPL=fp32: use the fp32-input MFMA kernel instead of the bf16x6 one
     // CNN
     std::vector<ConvLayer> cconv;          // conv_0 [, conv_1]
     std::vector<ConvLayer> clin;           // lin_0, dnn_0, dnn_1, lin_1 (present ones, in order)
@@ -215,7 +217,12 @@ int build_resnet(kws_handle* h) {
     h->required.insert("layers.output.bias");
     h->res8_eligible = d.n_layers == R8_LAYERS && C == R8_C && !d.use_dilation && d.pool_h == 4 && d.pool_w == 3 &&
                        d.freq == 40 && d.n_labels <= 256;
-    if (h->res8_eligible) h->r8_apk_host.assign(R8_APK_FLOATS, 0.f);
+    if (h->res8_eligible) {
+        h->r8_apk_host.assign(R8_APK_FLOATS, 0.f);
+        h->r8x_apk_host.assign(R8X_APK_SHORTS, 0);
+        const char* impl = std::getenv("KWS_RES8_IMPL");
+        h->res8_fp32_mfma = impl && std::strcmp(impl, "fp32") == 0;
+    }
     return KWS_OK;
 }
 
@@ -336,6 +343,7 @@ int finalize(kws_handle* h) {
                 }
             if ((rc = h->r8_bn.upload(tab.data(), tab.size() * 4))) return rc;
             if ((rc = h->r8_apk.upload(h->r8_apk_host.data(), h->r8_apk_host.size() * 4))) return rc;
+            if ((rc = h->r8x_apk.upload(h->r8x_apk_host.data(), h->r8x_apk_host.size() * 2))) return rc;
             std::vector<int> zc(1024);
             build_res8_zero_cells(zc.data());
             if ((rc = h->r8_zcells.upload(zc.data(), zc.size() * sizeof(int)))) return rc;
@@ -513,15 +521,20 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
     if ((rc = prof_mark(h, h->ev_model, s))) return rc;
     if (h->plan == PLAN_RESNET) {
         if (use_fused(h, T)) {
-            h->last_plan = "res8_fused";
-            Res8Params p{feat, logits, h->r8_w0a.as<float>(), h->r8_apk.as<f32x4>(), h->r8_bn.as<float>(),
-                         h->r8_zcells.as<int>(), h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq,
-                         h->d.n_labels, 0};
             static const int dbg = std::getenv("KWS_R8_DEBUG") ? std::atoi(std::getenv("KWS_R8_DEBUG")) : 0;
-            static const int grid_env = std::getenv("KWS_R8_GRID") ? std::atoi(std::getenv("KWS_R8_GRID")) : 512;
-            p.debug = dbg;
-            const int grid = std::min(B, grid_env);
-            HIP_TRY(launch_res8(p, grid, s));
+            if (h->res8_fp32_mfma) {
+                h->last_plan = "res8_fused_fp32mfma";
+                Res8Params p{feat, logits, h->r8_w0a.as<float>(), h->r8_apk.as<f32x4>(), h->r8_bn.as<float>(),
+                             h->r8_zcells.as<int>(), h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq,
+                             h->d.n_labels, dbg};
+                static const int grid_env = std::getenv("KWS_R8_GRID") ? std::atoi(std::getenv("KWS_R8_GRID")) : 512;
+                HIP_TRY(launch_res8(p, std::min(B, grid_env), s));
+            } else {
+                h->last_plan = "res8_fused";
+                Res8xParams p{feat, logits, h->r8_w0a.as<float>(), h->r8x_apk.p, h->r8_bn.as<float>(),
+                              h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq, h->d.n_labels, dbg};
+                HIP_TRY(launch_res8x(p, std::min(B, 256), s));
+            }
         } else {
             h->last_plan = "layerwise";
             if ((rc = run_resnet_layerwise(h, feat, B, T, logits, ws_act, s))) return rc;
@@ -621,6 +634,7 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
                     if ((rc = h->r8_w0a.upload(frag.data(), frag.size() * 4))) return rc;
                 } else {
                     pack_res8_layer(src, h->r8_apk_host.data() + (size_t)(idx - 1) * R8_GROUPS * 3 * 64 * 4);
+                    pack_res8x_layer(src, h->r8x_apk_host.data() + (size_t)(idx - 1) * R8X_KSTEPS * 3 * 3 * 64 * 8);
                 }
             }
         } else if (std::sscanf(name.c_str(), "layers.bn_%d.%31s", &idx, field) == 2) {

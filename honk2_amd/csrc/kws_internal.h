@@ -66,6 +66,25 @@ void pack_res8_layer(const float* w /*45x45x3x3*/, float* dst /*R8_GROUPS*3*64*4
 void pack_res8_conv0(const float* w /*45x9*/, float* dst /*3*3*64*/);
 void build_res8_zero_cells(int* dst /*1024*/);
 
+// ---------------------------------------------------------------- fused res8, bf16x6 matrix path (res8_bf16x6.hip)
+constexpr int R8X_KSTEPS = 14;      // 9 taps x 6 blocks of 8 input channels = 54 blocks, 4 per k-step of v_mfma_f32_16x16x32_bf16
+constexpr size_t R8X_APK_SHORTS = (size_t)R8_LAYERS * R8X_KSTEPS * 3 * 3 * 64 * 8;
+
+struct Res8xParams {
+    const float* feat;    // (B, 101, 40)
+    float* logits;        // (B, n_labels)
+    const float* w0a;     // conv_0 weight as fp32 A fragments (pack_res8_conv0)
+    const void* apk6;     // conv_1..6 weights split into three bf16 parts, fragment order (pack_res8x_layer)
+    const float* bn_tab;  // (6, 96): per layer scale[48], shift[48]
+    const float* out_w;   // (n_labels, 45)
+    const float* out_b;   // (n_labels)
+    int B, T, F, n_labels;
+    int debug;            // timing experiments only: 1 skip conv_0, 2 skip the MFMA loop
+};
+size_t res8x_lds_bytes();
+hipError_t launch_res8x(const Res8xParams& p, int grid, hipStream_t s);
+void pack_res8x_layer(const float* w /*45x45x3x3*/, unsigned short* dst /*R8X_KSTEPS*3*3*64*8*/);
+
 // ---------------------------------------------------------------- layer-wise kernels (layerwise.hip)
 struct ConvGeom {
     int B;                 // clips in this launch
