@@ -27,7 +27,8 @@ RES8 = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": Fal
 F_ALG_MODEL = 74.35e6          # FLOP / clip, conv + linear, 2 x MAC
 F_ALG_FRONTEND = 1.22e6        # FLOP / clip, FFT-based count
 B_ALG = 64048                  # HBM bytes / clip end to end: 16 000 fp32 samples in + 12 fp32 logits out
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix (= vector) peak
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input matrix (= fp32 vector) peak
+PEAK_BF16_MFMA_TFLOPS = 2516.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (spec); 2.0 PF sustained on this box (tools/coexec_probe_bf16)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -153,18 +154,28 @@ def main():
         k_ms = model_ms / max(calls, 1)
         f_ms = front_ms / max(calls, 1)
         achieved = F_ALG_MODEL * nloc / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        plan = model.plan_name()
+        if plan == "res8_fused":
+            # conv_1..6 run on the bf16 matrix cores with fp32-accurate 6-term products (x = x1+x2+x3 in bf16, six
+            # partial products, fp32 accumulate): every algorithmic MAC costs six bf16 MACs, so the roof for this
+            # arithmetic is the dense bf16 MFMA peak / 6.
+            peak, kern = PEAK_BF16_MFMA_TFLOPS / 6.0, "res8x_kernel (fused conv stack, bf16 MFMA x 6 terms, fp32 accumulate)"
+            note = ("peak = 2516 TFLOP/s dense bf16 / 6 terms; achieved is %.2fx the fp32-input MFMA roof of 157.3 TFLOP/s"
+                    % (achieved / PEAK_F32_MFMA_TFLOPS))
+        else:
+            peak, kern, note = PEAK_F32_MFMA_TFLOPS, "res8_kernel (fused conv stack, fp32-input MFMA)", ""
+        roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak, "traffic": None, "kernel_ms": k_ms, "launches": calls,
+                    "flop_per_launch": F_ALG_MODEL * nloc, "note": note}
         out = {
             "metric": "1s-clips/sec end-to-end (wav->logits), res8 GSCv2", "value": clips_per_s, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": ("f32 (bf16x6: fp32-accurate 6-term bf16 products, fp32 accumulate; fp32 front end)" if model.plan_name() == "res8_fused" else "f32"), "data": "synthetic",
             "config": {"workload": f"res8 fp32 wav->logits, global batch {args.batch} one-second 16 kHz clips "
                                    f"(BASELINE configs[3]), {nloc} clips/GPU, random-init weights",
                        "global_batch": args.batch, "clips_per_gpu": nloc, "n_samples": 16000,
                        "plan": model.plan_name(), "parallelism": f"dp{world} (clip sharding, logits all-gather)"},
-            "roofline": {"bound": "mfma", "kernel": "res8_kernel (fused conv stack, fp32 MFMA)", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "kernel_ms": k_ms, "launches": calls,
-                         "flop_per_launch": F_ALG_MODEL * nloc},
+            "roofline": roofline,
             "frontend": {"kernel": "frontend_kernel (STFT+mel+log, fp32 MFMA)", "kernel_ms": f_ms,
                          "hbm_GBps_algorithmic": (80160 * nloc / (f_ms * 1e-3) / 1e9) if f_ms > 0 else 0.0},
             "end_to_end": {"hbm_frac_of_8TBps": clips_per_s / world * B_ALG / (PEAK_HBM_GBS * 1e9),
