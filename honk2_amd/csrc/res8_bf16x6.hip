@@ -91,40 +91,53 @@ struct XCtx {
     bool xvalid;
 };
 
-struct Frags {
+struct AFrags {
     u32x4 a[3][3];   // [channel tile][part]
     u32x4 ax[3];     // extra tile's channel tile
-    u32x4 b[6][3];   // [position tile][part]
+};
+struct BFrag {
+    u32x4 p[3];      // the three bf16 parts of one position tile's B fragment
 };
 
-__device__ __forceinline__ void load_frags(Frags& f, const XCtx& c, const u32x4* A, int s) {
-    // block bi = 4 s + g of this lane's k-slot: tap = bi / 6, channel block = bi % 6 (blocks 54, 55 are zero padding)
-    int bi = 4 * s + c.g;
-    bi = bi < 54 ? bi : 53;
+// byte offset (within the map) of this lane's k-slot at k-step s: block bi = 4 s + g -> tap = bi / 6, channel block bi % 6
+__device__ __forceinline__ int step_boff(int s, int g) {
+    int bi = 4 * s + g;
+    bi = bi < 54 ? bi : 53;   // blocks 54, 55 are zero-weight padding: re-read a valid block
     const int tap = bi / 6, cblk = bi - 6 * tap, ty = tap / 3, tx = tap - 3 * ty;
-    const int boff = ((ty - 1) * R8_RS + (tx - 1)) * CELL_B + cblk * 16;
+    return ((ty - 1) * R8_RS + (tx - 1)) * CELL_B + cblk * 16;
+}
+__device__ __forceinline__ void load_a(AFrags& f, const u32x4* A, int s, int mx) {
     const u32x4* As = A + (size_t)s * A_STEP;
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int pt = 0; pt < 3; ++pt) f.a[m][pt] = As[(m * 3 + pt) * 64];
 #pragma unroll
-    for (int pt = 0; pt < 3; ++pt) f.ax[pt] = As[(c.mx * 3 + pt) * 64];
+    for (int pt = 0; pt < 3; ++pt) f.ax[pt] = As[(mx * 3 + pt) * 64];
+}
+__device__ __forceinline__ void load_b(BFrag& b, const char* lds, int addr) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-#pragma unroll
-        for (int pt = 0; pt < 3; ++pt) f.b[j][pt] = *reinterpret_cast<const u32x4*>(c.lds + c.qb[j] + boff + pt * PART_B);
-    __builtin_amdgcn_sched_barrier(0);   // keep this prefetch ABOVE the MFMAs it overlaps
+    for (int pt = 0; pt < 3; ++pt) b.p[pt] = *reinterpret_cast<const u32x4*>(lds + addr + pt * PART_B);
 }
 
-__device__ __forceinline__ void mfma_frags(const Frags& f, f32x4 (&acc)[5][3], f32x4& accx) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-        for (int m = 0; m < 3; ++m) { MF6(f.a[m], f.b[j], acc[j][m]) }
-    MF6(f.ax, f.b[5], accx)
-    __builtin_amdgcn_sched_barrier(0);
-}
+// One k-step: 16 tiles x 6 terms = 96 MFMAs.  B fragments are fetched ONE position tile ahead (three ds_read_b128 in
+// flight -- the LDS counter is 4 bits, a whole k-step's 18 reads cannot be outstanding); `bnext_addr0` is tile 0 of
+// the NEXT k-step.  A fragments of the next k-step were requested by the caller before this step's MFMAs.
+#define X_STEP(AF, BOFF, BOFF_NEXT)                                                   \
+    {                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 6; ++j) {                               \
+            BFrag& bcur = (j & 1) ? bb1 : bb0;                                        \
+            BFrag& bnxt = (j & 1) ? bb0 : bb1;                                        \
+            load_b(bnxt, c.lds, j < 5 ? c.qb[j + 1] + (BOFF) : c.qb[0] + (BOFF_NEXT)); \
+            __builtin_amdgcn_sched_barrier(0);                                        \
+            if (j < 5) {                                                              \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) { MF6(AF.a[m], bcur.p, acc[j][m]) } \
+            } else {                                                                  \
+                MF6(AF.ax, bcur.p, accx)                                              \
+            }                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                        \
+        }                                                                             \
+    }
 
 template <bool EVEN, bool LAST>
 __device__ __forceinline__ void x_layer(const Res8xParams& p, const XCtx& c, int layer, int clip, f32x4 (&prev)[5][3],
@@ -138,14 +151,19 @@ __device__ __forceinline__ void x_layer(const Res8xParams& p, const XCtx& c, int
     accx = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const u32x4* A = reinterpret_cast<const u32x4*>(p.apk6) + (size_t)layer * KSTEPS * A_STEP + c.lane;
-    Frags f0, f1;
-    load_frags(f0, c, A, 0);
+    AFrags fa0, fa1;
+    BFrag bb0, bb1;   // ping-pong over position tiles; 6 tiles per step keeps the parity aligned across steps
+    load_a(fa0, A, 0, mx);
+    load_b(bb0, c.lds, c.qb[0] + step_boff(0, g));
     if (!(p.debug & 2)) {
         for (int s = 0; s < KSTEPS; s += 2) {
-            load_frags(f1, c, A, s + 1);
-            mfma_frags(f0, acc, accx);
-            load_frags(f0, c, A, s + 2 < KSTEPS ? s + 2 : KSTEPS - 1);   // last one is a harmless re-read
-            mfma_frags(f1, acc, accx);
+            const int o0 = step_boff(s, g), o1 = step_boff(s + 1, g), o2 = step_boff(s + 2 < KSTEPS ? s + 2 : KSTEPS - 1, g);
+            load_a(fa1, A, s + 1, mx);
+            __builtin_amdgcn_sched_barrier(0);
+            X_STEP(fa0, o0, o1)
+            load_a(fa0, A, s + 2 < KSTEPS ? s + 2 : KSTEPS - 1, mx);   // last one is a harmless re-read
+            __builtin_amdgcn_sched_barrier(0);
+            X_STEP(fa1, o1, o2)
         }
     }
 
