@@ -116,6 +116,24 @@ def test_res8_fused_equals_layerwise_and_oracle_on_a_larger_batch(torch_cuda, mo
     assert (a.argmax(1) == want.argmax(1))[clear].all() and clear.mean() > 0.9
 
 
+def test_res8_fp32_mfma_kernel_agrees_with_bf16x6_kernel(torch_cuda, monkeypatch):
+    """Two independent fused kernels: the default one forms fp32-accurate products from six bf16 MFMA terms, the
+    other (KWS_RES8_IMPL=fp32) uses the fp32-input MFMA.  Both must match the reference and each other."""
+    torch = torch_cuda
+    tag, name, cfg, sd, feats, z = load_golden_model("model_resnet__res8.npz")
+    x = torch.from_numpy(feats).cuda()
+    a = _build(torch, name, cfg, sd)
+    ya = a(x).cpu().numpy()
+    assert a.plan_name() == "res8_fused"
+    monkeypatch.setenv("KWS_RES8_IMPL", "fp32")
+    b = _build(torch, name, cfg, sd)
+    yb = b(x).cpu().numpy()
+    assert b.plan_name() == "res8_fused_fp32mfma"
+    for y in (ya, yb):
+        assert np.abs(y - z["logits"]).max() < LOGIT_TOL and (y.argmax(1) == z["logits"].argmax(1)).all()
+    assert np.abs(ya - yb).max() < 2e-5
+
+
 def test_wav_to_logits_end_to_end(torch_cuda):
     torch = torch_cuda
     from oracle import frontend, models, weights
