@@ -102,8 +102,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
-    rank, world = dist_utils.init_from_env("nccl")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # KWS_BENCH_BACKEND / KWS_BENCH_ONE_DEVICE are rehearsal knobs only (several ranks on one GPU over gloo, to exercise
+    # the N > 1 code path on a single-GPU box); the real multi-GPU run uses RCCL with one GPU per rank.
+    rank, world = dist_utils.init_from_env(os.environ.get("KWS_BENCH_BACKEND", "nccl"))
+    local = 0 if os.environ.get("KWS_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 

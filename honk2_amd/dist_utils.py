@@ -31,7 +31,7 @@ def init_from_env(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))   # one GPU per rank, before the communicator exists
     dist.init_process_group(backend=backend)
     return world()
 
