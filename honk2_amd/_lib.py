@@ -16,7 +16,7 @@ KWS_DTYPE_F32 = 0
 # every symbol include/kws.h declares (tests check the library exports exactly these)
 EXPORTS = (
     "kws_create", "kws_destroy", "kws_load_weights", "kws_workspace_bytes", "kws_set_workspace", "kws_num_frames",
-    "kws_mfcc", "kws_forward", "kws_forward_wav", "kws_eval_batch", "kws_plan_name", "kws_profile_enable",
+    "kws_mfcc", "kws_mfcc_pcm16", "kws_forward", "kws_forward_wav", "kws_forward_pcm16", "kws_eval_batch", "kws_plan_name", "kws_profile_enable",
     "kws_profile_read", "kws_last_error", "kws_abi_version",
 )
 
@@ -71,6 +71,10 @@ def load():
     lib.kws_num_frames.restype = ci
     lib.kws_mfcc.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.kws_mfcc.restype = ci
+    lib.kws_mfcc_pcm16.argtypes = [vp, vp, vp, C.c_float, ci, ci, vp, vp]
+    lib.kws_mfcc_pcm16.restype = ci
+    lib.kws_forward_pcm16.argtypes = [vp, vp, vp, C.c_float, ci, ci, vp, vp]
+    lib.kws_forward_pcm16.restype = ci
     lib.kws_forward.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.kws_forward.restype = ci
     lib.kws_forward_wav.argtypes = [vp, vp, ci, ci, vp, vp]
@@ -180,16 +184,39 @@ class Engine:
     def num_frames(self, n_samples):
         return int(self.lib.kws_num_frames(self.handle, int(n_samples)))
 
-    def mfcc(self, wav):
+    def _wave_args(self, wav, noise, noise_pct):
+        """-> (tensor, is_pcm16, noise tensor or None).  int16 tensors take the fused PCM path."""
         import torch
-        wav = self._check_in(wav, 2, "wav")
+        if not (isinstance(wav, torch.Tensor) and wav.is_cuda):
+            raise RuntimeError("honk2_amd: wav must be a CUDA(ROCm) tensor; there is no CPU path")
+        if wav.dim() != 2:
+            raise ValueError(f"honk2_amd: wav must have 2 dimensions, got {tuple(wav.shape)}")
+        pcm = wav.dtype == torch.int16
+        wav = wav.contiguous() if pcm else wav.to(dtype=torch.float32).contiguous()
+        if noise is not None:
+            noise = self._check_in(noise, 2, "noise")
+            if noise.shape != wav.shape:
+                raise ValueError("honk2_amd: noise must have the shape of wav")
+            if not pcm:                                   # float input: mix on the device with torch (plumbing)
+                wav, noise = wav + noise * float(noise_pct), None
+        return wav, pcm, noise
+
+    def mfcc(self, wav, noise=None, noise_pct=0.0):
+        import torch
+        wav, pcm, noise = self._wave_args(wav, noise, noise_pct)
         b, n = wav.shape
         t = self.num_frames(n)
         out = torch.empty((b, t, self.desc.n_mels), dtype=torch.float32, device=wav.device)
         if b == 0:
             return out
-        check(self.lib.kws_mfcc(self.handle, C.c_void_p(wav.data_ptr()), b, n, C.c_void_p(out.data_ptr()),
-                                self._stream()), "kws_mfcc")
+        if pcm:
+            check(self.lib.kws_mfcc_pcm16(self.handle, C.c_void_p(wav.data_ptr()),
+                                          C.c_void_p(noise.data_ptr()) if noise is not None else None,
+                                          C.c_float(noise_pct), b, n, C.c_void_p(out.data_ptr()), self._stream()),
+                  "kws_mfcc_pcm16")
+        else:
+            check(self.lib.kws_mfcc(self.handle, C.c_void_p(wav.data_ptr()), b, n, C.c_void_p(out.data_ptr()),
+                                    self._stream()), "kws_mfcc")
         return out
 
     def forward(self, feat):
@@ -207,9 +234,9 @@ class Engine:
                                    self._stream()), "kws_forward")
         return out
 
-    def forward_wav(self, wav, out=None):
+    def forward_wav(self, wav, out=None, noise=None, noise_pct=0.0):
         import torch
-        wav = self._check_in(wav, 2, "wav")
+        wav, pcm, noise = self._wave_args(wav, noise, noise_pct)
         b, n = wav.shape
         if b:
             self._ensure_ws(b, self.num_frames(n))
@@ -217,8 +244,14 @@ class Engine:
             out = torch.empty((b, self.desc.n_labels), dtype=torch.float32, device=wav.device)
         if b == 0:
             return out
-        check(self.lib.kws_forward_wav(self.handle, C.c_void_p(wav.data_ptr()), b, n, C.c_void_p(out.data_ptr()),
-                                       self._stream()), "kws_forward_wav")
+        if pcm:
+            check(self.lib.kws_forward_pcm16(self.handle, C.c_void_p(wav.data_ptr()),
+                                             C.c_void_p(noise.data_ptr()) if noise is not None else None,
+                                             C.c_float(noise_pct), b, n, C.c_void_p(out.data_ptr()), self._stream()),
+                  "kws_forward_pcm16")
+        else:
+            check(self.lib.kws_forward_wav(self.handle, C.c_void_p(wav.data_ptr()), b, n,
+                                           C.c_void_p(out.data_ptr()), self._stream()), "kws_forward_wav")
         return out
 
     def eval_batch(self, logits, target, stats, loss_sum):

@@ -690,18 +690,29 @@ int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes) {
     return KWS_OK;
 }
 
-int kws_mfcc(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_feat, void* stream) {
-    if (!h || !d_wav || !d_feat || B < 0) return fail(KWS_EINVAL, "bad argument");
+static int mfcc_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, const float* d_noise, float noise_pct,
+                    int B, int n_samples, float* d_feat, void* stream) {
+    if (!h || (!d_wav && !d_pcm) || !d_feat || B < 0) return fail(KWS_EINVAL, "bad argument");
     if (n_samples <= FE_NFFT / 2) return fail(KWS_EINVAL, "clip shorter than the reflect padding (n_fft/2 + 1 samples needed)");
     if (h->d.n_mels != h->d.freq && h->plan != PLAN_FRONTEND_ONLY) return fail(KWS_EINVAL, "n_mels != model frequency bins");
     const int T = 1 + n_samples / FE_HOP;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
     if ((rc = prof_mark(h, h->ev_front, s))) return rc;
-    FrontendParams p{d_wav, d_feat, h->dft.as<f32x4>(), h->hann.as<float>(), h->melw.as<float>(), h->mel_lo.as<int>(),
-                     h->mel_hi.as<int>(), B, n_samples, T, h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, h->mel_maxw};
+    FrontendParams p{d_wav, reinterpret_cast<const short*>(d_pcm), d_noise, noise_pct, d_feat, h->dft.as<f32x4>(),
+                     h->hann.as<float>(), h->melw.as<float>(), h->mel_lo.as<int>(), h->mel_hi.as<int>(), B, n_samples, T,
+                     h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, h->mel_maxw};
     HIP_TRY(launch_frontend(p, s));
     return prof_mark(h, h->ev_front, s);
+}
+
+int kws_mfcc(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_feat, void* stream) {
+    return mfcc_any(h, d_wav, nullptr, nullptr, 0.f, B, n_samples, d_feat, stream);
+}
+
+int kws_mfcc_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise, float noise_pct, int B, int n_samples,
+                   float* d_feat, void* stream) {
+    return mfcc_any(h, nullptr, d_pcm, d_noise, noise_pct, B, n_samples, d_feat, stream);
 }
 
 int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits, void* stream) {
@@ -717,17 +728,27 @@ int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits,
                      static_cast<hipStream_t>(stream));
 }
 
-int kws_forward_wav(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_logits, void* stream) {
-    if (!h || !d_wav || !d_logits || B < 0) return fail(KWS_EINVAL, "bad argument");
+static int forward_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, const float* d_noise, float noise_pct,
+                       int B, int n_samples, float* d_logits, void* stream) {
+    if (!h || (!d_wav && !d_pcm) || !d_logits || B < 0) return fail(KWS_EINVAL, "bad argument");
     int rc = finalize(h);
     if (rc) return rc;
     const int T = 1 + n_samples / FE_HOP;
     const size_t fb = feat_bytes(h, B, T), ab = act_bytes(h, B, T);
     if ((rc = check_ws(h, fb + ab))) return rc;
     float* feat = static_cast<float*>(h->ws);
-    if ((rc = kws_mfcc(h, d_wav, B, n_samples, feat, stream))) return rc;
+    if ((rc = mfcc_any(h, d_wav, d_pcm, d_noise, noise_pct, B, n_samples, feat, stream))) return rc;
     char* ws_act = ab ? static_cast<char*>(h->ws) + fb : nullptr;
     return run_model(h, feat, B, T, d_logits, ws_act, static_cast<hipStream_t>(stream));
+}
+
+int kws_forward_wav(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_logits, void* stream) {
+    return forward_any(h, d_wav, nullptr, nullptr, 0.f, B, n_samples, d_logits, stream);
+}
+
+int kws_forward_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise, float noise_pct, int B, int n_samples,
+                      float* d_logits, void* stream) {
+    return forward_any(h, nullptr, d_pcm, d_noise, noise_pct, B, n_samples, d_logits, stream);
 }
 
 int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target, int B, int64_t* d_stats,

@@ -25,7 +25,10 @@ constexpr int FE_PSTRIDE = 116;     // row stride (words) of the power tile in L
 constexpr size_t FE_TABLE_FLOATS = (size_t)4 * FE_GROUPS * 4 * 64 * 4;
 
 struct FrontendParams {
-    const float* wav;     // (B, n_samples)
+    const float* wav;     // (B, n_samples) fp32, or nullptr when pcm is given
+    const short* pcm;     // (B, n_samples) int16 PCM, or nullptr
+    const float* noise;   // (B, n_samples) additive noise clips, or nullptr
+    float noise_pct;
     float* feat;          // (B, T, n_mels)
     const f32x4* dft;     // packed cos/sin table, FE_TABLE_FLOATS floats
     const float* hann;    // (FE_STEPS*4, 2): h[j], h[240-j]

@@ -93,11 +93,13 @@ class BaseModel(ABC, nn.Module):
         with torch.no_grad():
             return self.engine().forward(x)
 
-    def forward_wav(self, wav, out=None):
-        """(B, n_samples) float32 waveforms on the GPU -> logits, front end fused in (``kws_forward_wav``)."""
+    def forward_wav(self, wav, out=None, noise=None, noise_pct=0.0):
+        """(B, n_samples) waveforms on the GPU -> logits, front end fused in.  float32 input -> ``kws_forward_wav``;
+        int16 PCM input -> ``kws_forward_pcm16`` (x/32768, optional ``+ noise * noise_pct`` as
+        ``GSCDataset.__getitem__`` does, both inside the front end's staging load)."""
         self._require_eval()
         with torch.no_grad():
-            return self.engine().forward_wav(wav, out)
+            return self.engine().forward_wav(wav, out, noise, noise_pct)
 
     def plan_name(self):
         return self.engine().plan_name()

@@ -37,9 +37,9 @@ class AudioProcessor(object):
     def num_frames(self, n_samples):
         return 1 + n_samples // self.hop_length
 
-    def compute_mfccs_batch(self, wav):
-        """(B, n) float tensor on the GPU -> (B, T, n_mels) float32 tensor on the GPU."""
-        return self._get_engine().mfcc(wav)
+    def compute_mfccs_batch(self, wav, noise=None, noise_pct=0.0):
+        """(B, n) float32 or int16-PCM tensor on the GPU -> (B, T, n_mels) float32 tensor on the GPU."""
+        return self._get_engine().mfcc(wav, noise, noise_pct)
 
     def compute_mfccs(self, data):
         import torch

@@ -12,6 +12,7 @@
  *   kws_create        <- ResNet.__init__ / CNN.__init__      model/resnet.py:11-36, model/cnn.py:12-77
  *                        + AudioProcessor.__init__            utils/audio_processor.py:8-16
  *   kws_load_weights  <- model.load_state_dict               utils/workspace.py:58-61
+ *   kws_*_pcm16       <- librosa.load int16->float + `data += noise * noise_pct`   dataset/gsc_dataset.py:163-174
  *   kws_eval_batch    <- loss_fn + metric.accumulate          run/test.py:28-33, loss_function.py:6-9,
  *                                                             metric/acc.py:14-24, metric/per_class_acc.py:14-45
  *
@@ -25,7 +26,9 @@
  *     thread-local human-readable message for the last failure on the calling thread.
  *   - a handle is bound to the HIP device that was current at kws_create and is not re-entrant
  *     (one in-flight call per handle); distinct handles are independent.
- *   - all arithmetic is fp32 (KWS_DTYPE_F32): fp32-input MFMA + fp32 VALU, fp32 accumulation.
+ *   - KWS_DTYPE_F32: results are fp32-accurate (fp32 accumulation everywhere).  Products are formed either by the
+ *     fp32-input MFMA / fp32 VALU, or -- fused res8 -- on the bf16 matrix cores as six exact bf16 x bf16 partial
+ *     products of three-way bf16 splits of both fp32 operands (error <= 2^-24 |ab|, i.e. at the fp32 rounding level).
  */
 #ifndef KWS_H_
 #define KWS_H_
@@ -102,11 +105,20 @@ int kws_num_frames(const kws_handle* h, int n_samples);
 /* wav (B, n_samples) fp32 -> feat (B, T, n_mels) fp32, feat[b,t,f] = 2*ln(mel[f,t]) (0 where mel == 0). */
 int kws_mfcc(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_feat, void* stream);
 
+/* Same from 16-bit PCM: sample = pcm / 32768 (+ d_noise[b, i] * noise_pct when d_noise != NULL; d_noise is (B, n_samples)
+ * fp32).  The conversion and the mix happen inside the front end's staging load. */
+int kws_mfcc_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise, float noise_pct, int B, int n_samples,
+                   float* d_feat, void* stream);
+
 /* feat (B, T, freq) fp32 -> logits (B, n_labels) fp32. */
 int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits, void* stream);
 
 /* wav (B, n_samples) fp32 -> logits (B, n_labels) fp32 (feature maps stay in the workspace). */
 int kws_forward_wav(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_logits, void* stream);
+
+/* pcm16 (B, n_samples) [+ noise] -> logits. */
+int kws_forward_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise, float noise_pct, int B, int n_samples,
+                      float* d_logits, void* stream);
 
 /* Evaluation tail, fused: adds to d_stats (int64[2 + 2*n_labels] = correct, total, per-class correct[n],
  * per-class total[n]) and to d_loss_sum (double[1]: sum over clips of the cross-entropy, natural log). */

@@ -151,6 +151,37 @@ def test_wav_to_logits_end_to_end(torch_cuda):
     assert np.abs(model(feats).cpu().numpy() - got).max() < 1e-5
 
 
+def test_pcm16_input_with_noise_mix(torch_cuda):
+    """16-bit PCM input path (x/32768 [+ noise*pct], dataset/gsc_dataset.py:163-174) fused into the front end."""
+    torch = torch_cuda
+    from honk2_amd.utils import AudioProcessor
+    from oracle import frontend, models, weights
+    cfg = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 12}
+    sd = weights.make_state_dict("ResNet", cfg, seed=7)
+    model = _build(torch, "ResNet", cfg, sd)
+    rng = np.random.default_rng(3)
+    pcm = np.clip(rng.normal(0, 3000, size=(24, 16000)), -32768, 32767).astype(np.int16)
+    pcm[5] = 0                                                    # digital silence
+    noise = (0.05 * rng.standard_normal((24, 16000))).astype(np.float32)
+    pct = np.float32(0.1)
+    as_float = pcm.astype(np.float32) / np.float32(32768.0)
+    mixed = as_float + noise * pct                                # float32 arithmetic, as the reference's `data += ...`
+    d_pcm, d_noise = torch.from_numpy(pcm).cuda(), torch.from_numpy(noise).cuda()
+    # no noise: identical to feeding the converted floats (the conversion is exact)
+    a = model.forward_wav(d_pcm)
+    b = model.forward_wav(torch.from_numpy(as_float).cuda())
+    assert torch.equal(a, b)
+    # with noise: identical to feeding the mixed floats, and within tolerance of the oracle
+    c = model.forward_wav(d_pcm, noise=d_noise, noise_pct=float(pct))
+    d = model.forward_wav(torch.from_numpy(mixed).cuda())
+    assert torch.equal(c, d)
+    want = models.forward_numpy("ResNet", cfg, sd, frontend.compute_mfccs_batch(mixed, "f64"), np.float64)
+    assert np.abs(c.cpu().numpy() - want).max() < LOGIT_TOL and (c.cpu().numpy().argmax(1) == want.argmax(1)).all()
+    feats = AudioProcessor().compute_mfccs_batch(d_pcm, noise=d_noise, noise_pct=float(pct)).cpu().numpy()
+    assert np.abs(feats - frontend.compute_mfccs_batch(mixed, "f64")).max() < 1e-3
+    assert np.array_equal(AudioProcessor().compute_mfccs_batch(d_pcm)[5].cpu().numpy(), np.zeros((101, 40), np.float32))
+
+
 def test_size_independent_properties_at_full_batch(torch_cuda):
     """BASELINE size (8192 clips/GPU): batch-composition independence and repeatability."""
     torch = torch_cuda
