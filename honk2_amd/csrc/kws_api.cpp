@@ -55,8 +55,8 @@ enum Plan { PLAN_FRONTEND_ONLY, PLAN_RESNET, PLAN_CNN };
 
 struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the layer-wise plans
     ConvGeom g{};           // B/H/W/Ho/Wo filled per call for ResNet, at create for CNN
-    DevMem apk, bias, border;
-    bool has_bias = false, has_border = false;
+    DevMem apk, apk16, bias, border;
+    bool has_bias = false, has_border = false, use_x = false;   // use_x: bf16x6 kernel available for this layer
     std::vector<float> w_host;   // ResNet: raw weights kept until finalize() folds the previous BatchNorm in
 };
 
@@ -277,7 +277,28 @@ int build_cnn(kws_handle* h) {
 int upload_packed(ConvLayer& L, const float* w) {
     std::vector<float> pk;
     pack_conv_weights(L.g, w, pk);
-    return L.apk.upload(pk.data(), pk.size() * sizeof(float));
+    int rc = L.apk.upload(pk.data(), pk.size() * sizeof(float));
+    if (rc) return rc;
+    conv_bf16x6_geometry(L.g);
+    static const bool force_fp32 = std::getenv("KWS_LAYERWISE_IMPL") && std::strcmp(std::getenv("KWS_LAYERWISE_IMPL"), "fp32") == 0;
+    L.use_x = !force_fp32 && conv_bf16x6_supported(L.g);
+    if (L.use_x) {
+        std::vector<unsigned short> pk16;
+        pack_conv_weights_bf16x6(L.g, w, pk16);
+        rc = L.apk16.upload(pk16.data(), pk16.size() * sizeof(unsigned short));
+    }
+    return rc;
+}
+
+// one conv launch through whichever kernel the layer supports (geometry fields B/H/W already set in g)
+int launch_layer(const ConvLayer& L, const ConvGeom& g, ConvArgs a, hipStream_t s) {
+    if (L.use_x) {
+        a.apk16 = L.apk16.as<unsigned short>();
+        HIP_TRY(launch_conv_bf16x6(g, a, s));
+    } else {
+        HIP_TRY(launch_conv(g, a, s));
+    }
+    return KWS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- finalize (lazy)
@@ -380,18 +401,18 @@ int chunk_clips(size_t per_clip_elems, int B) {
 }
 
 // Linears (flat Cin == 1 "convs") over a chunk of clips launch only B/256 workgroups; split K so the chip is filled.
-int plan_ksplit(const ConvGeom& g, int nb) {
+int plan_ksplit(const ConvGeom& g, int nb, int steps) {
     if (!(g.kx_inner && g.ph == 0 && g.pw == 0)) return 1;
     const long long wgs = (((long long)nb * g.Ho * g.Wo + 255) / 256) * ((g.mtiles + g.MT - 1) / g.MT);
-    if (wgs >= 256 || g.ksteps < 64) return 1;
-    int ks = (int)std::min<long long>((1024 + wgs - 1) / wgs, g.ksteps / 32);
+    if (wgs >= 256 || steps < 64) return 1;
+    int ks = (int)std::min<long long>((1024 + wgs - 1) / wgs, steps / 16);
     return std::max(1, std::min(ks, 256));
 }
 
 size_t cnn_partial_bytes(const kws_handle* h, int cb) {
     size_t mx = 0;
     for (const auto& L : h->clin) {
-        const int ks = plan_ksplit(L.g, cb);
+        const int ks = std::max(plan_ksplit(L.g, cb, L.g.ksteps), plan_ksplit(L.g, cb, std::max(L.g.x_ksteps, 1)));
         if (ks > 1) mx = std::max(mx, (size_t)ks * cb * L.g.Cout * L.g.Ho * L.g.Wo * 4);
     }
     return align256(mx);
@@ -403,11 +424,12 @@ size_t act_bytes(const kws_handle* h, int B, int T) {
         const ResnetShape s = resnet_shape(h, T);
         const size_t full = (size_t)s.C * s.T * s.F, small = (size_t)s.C * s.H * s.W;
         const int cb = chunk_clips(full, B);
-        return (s.pooled ? align256(full * cb * 4) : 0) + 2 * align256(small * cb * 4);
+        // + slack: padded channel blocks of the last clip read (and discard) up to 7 planes past a tensor's end
+        return (s.pooled ? align256(full * cb * 4) : 0) + 2 * align256(small * cb * 4) + align256((size_t)8 * s.T * s.F * 4 + 4096);
     }
     if (h->plan == PLAN_CNN) {
         const int cb = chunk_clips(h->cnn_max_elems, B);
-        return 2 * align256(h->cnn_max_elems * cb * 4) + cnn_partial_bytes(h, cb);
+        return 2 * align256(h->cnn_max_elems * cb * 4) + cnn_partial_bytes(h, cb) + align256((size_t)8 * h->d.time * h->d.freq * 4 + 4096);
     }
     return 0;
 }
@@ -434,22 +456,23 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
     float* X = (float*)ws; ws += align256(small * cb * 4);
     float* Y = (float*)ws;
     const int C = sh.C;
+    int rc;
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
         // conv_0 + ReLU (+ AvgPool)
         ConvGeom g0 = h->rconv[0].g;
         set_spatial(g0, nb, sh.T, sh.F);
-        ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr};
-        HIP_TRY(launch_conv(g0, a0, s));
+        ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr, nullptr};
+        if ((rc = launch_layer(h->rconv[0], g0, a0, s))) return rc;
         if (sh.pooled) HIP_TRY(launch_pool(bufA, X, nb * C, sh.T, sh.F, d.pool_h, d.pool_w, 0, s));
         // conv_i: odd i writes Y from X, even i accumulates into X from Y (prev_x lives in X)
         for (int i = 1; i <= d.n_layers; ++i) {
             ConvGeom g = h->rconv[i].g;
             set_spatial(g, nb, sh.H, sh.W);
             const bool even = (i % 2) == 0;
-            ConvArgs a{even ? Y : X, even ? X : Y, h->rconv[i].apk.as<float>(), nullptr, nullptr,
+            ConvArgs a{even ? Y : X, even ? X : Y, h->rconv[i].apk.as<float>(), nullptr, nullptr, nullptr,
                        h->rconv[i].has_border ? h->rconv[i].border.as<float>() : nullptr};
-            HIP_TRY(launch_conv(g, a, s));
+            if ((rc = launch_layer(h->rconv[i], g, a, s))) return rc;
         }
         const float* fin = (d.n_layers % 2 == 0) ? X : Y;
         HIP_TRY(launch_mean_linear(fin, logits + (size_t)b0 * d.n_labels, nb, C, sh.H * sh.W,
@@ -460,24 +483,25 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
     return KWS_OK;
 }
 
-int launch_conv_auto(ConvGeom g, ConvArgs a, int nb, float* partial, size_t partial_bytes, hipStream_t s) {
+int launch_conv_auto(const ConvLayer& L, ConvGeom g, ConvArgs a, int nb, float* partial, size_t partial_bytes, hipStream_t s) {
     g.B = nb;
-    g.ksplit = plan_ksplit(g, nb);
+    const int steps = L.use_x ? g.x_ksteps : g.ksteps;
+    g.ksplit = plan_ksplit(g, nb, steps);
     if (g.ksplit > 1) {
-        g.ksteps_split = (g.ksteps + g.ksplit - 1) / g.ksplit;
-        g.ksplit = (g.ksteps + g.ksteps_split - 1) / g.ksteps_split;
+        g.ksteps_split = (steps + g.ksplit - 1) / g.ksplit;
+        g.ksplit = (steps + g.ksteps_split - 1) / g.ksteps_split;
         const long long total = (long long)nb * g.Cout * g.Ho * g.Wo;
         if (!partial || (size_t)g.ksplit * total * 4 > partial_bytes) g.ksplit = 1;   // no room: fall back to one pass
         else {
             a.partial = partial;
-            HIP_TRY(launch_conv(g, a, s));
+            int rc = launch_layer(L, g, a, s);
+            if (rc) return rc;
             HIP_TRY(launch_splitk_reduce(partial, a.out, a.bias, g.ksplit, total, g.Cout, g.Ho * g.Wo, g.relu, s));
             return KWS_OK;
         }
     }
-    g.ksteps_split = g.ksteps;
-    HIP_TRY(launch_conv(g, a, s));
-    return KWS_OK;
+    g.ksteps_split = steps;
+    return launch_layer(L, g, a, s);
 }
 
 int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
@@ -496,8 +520,9 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             ConvGeom g = h->cconv[i].g;
             g.B = nb;
             float* conv_out_buf = other(cur);
-            ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), h->cconv[i].bias.as<float>(), nullptr, nullptr};
-            HIP_TRY(launch_conv(g, a, s));
+            ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), nullptr, h->cconv[i].bias.as<float>(), nullptr, nullptr};
+            int rcc = launch_layer(h->cconv[i], g, a, s);
+            if (rcc) return rcc;
             float* pooled = other(conv_out_buf);
             HIP_TRY(launch_pool(conv_out_buf, pooled, nb * g.Cout, g.Ho, g.Wo, d.pool_kh[i], d.pool_kw[i], 1, s));
             cur = pooled;
@@ -507,8 +532,8 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             g.B = nb;
             const bool last = i + 1 == h->clin.size();
             float* dst = last ? logits + (size_t)b0 * d.n_labels : other(cur);
-            ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), h->clin[i].bias.as<float>(), nullptr, nullptr};
-            int rc = launch_conv_auto(g, a, nb, part, part_bytes, s);
+            ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), nullptr, h->clin[i].bias.as<float>(), nullptr, nullptr};
+            int rc = launch_conv_auto(h->clin[i], g, a, nb, part, part_bytes, s);
             if (rc) return rc;
             cur = dst;
         }

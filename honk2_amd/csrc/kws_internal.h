@@ -100,6 +100,9 @@ struct ConvGeom {
     int mtiles;            // ceil(Cout/16)
     int MT;                // m-tiles per wave (1..4); grid.y = ceil(mtiles/MT)
     int relu, accumulate;  // epilogue: ReLU; out += value (residual kept in the output buffer)
+    int x_blocks_per_row;  // bf16x6 kernel: blocks of 8 per tap (ceil(Cin/8)) or per kernel row (ceil(kw/8))
+    int x_blocks;          // total K blocks of 8
+    int x_ksteps;          // ceil(x_blocks / 4): k-steps of v_mfma_f32_16x16x32_bf16
     int ksplit;            // > 1: K range split over blockIdx.z (flat Cin == 1 mode only); partial sums go to ConvArgs::partial
     int ksteps_split;      // k-steps per split
 };
@@ -107,6 +110,7 @@ struct ConvArgs {
     const float* in;       // (B, Cin, H, W)
     float* out;            // (B, Cout, Ho, Wo)
     const float* apk;      // packed weights [mgroup][kstep][MT][64] (previous layer's BN scale already folded in)
+    const unsigned short* apk16;   // the same weights split into three bf16 parts for conv_bf16x6_kernel, or nullptr
     const float* bias;     // (Cout) or nullptr
     float* partial;        // (ksplit, B, Cout, Ho*Wo) raw partial sums when ksplit > 1 (then reduced by launch_splitk_reduce)
     const float* border;   // (16, Cout) or nullptr: previous layer's BN shift summed over the in-bounds taps, by border class
@@ -114,6 +118,11 @@ struct ConvArgs {
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, hipStream_t s);
 void pack_conv_weights(const ConvGeom& g, const float* w /*Cout,Cin,kh,kw*/, std::vector<float>& dst);
 int choose_mt(int mtiles);
+// bf16x6 variant (layerwise_bf16x6.hip): same contract; supported for Cin > 1 and for unpadded Cin == 1 convs / Linears
+bool conv_bf16x6_supported(const ConvGeom& g);
+void conv_bf16x6_geometry(ConvGeom& g);
+hipError_t launch_conv_bf16x6(const ConvGeom& g, const ConvArgs& a, hipStream_t s);
+void pack_conv_weights_bf16x6(const ConvGeom& g, const float* w, std::vector<unsigned short>& dst);
 // out[i] = (relu?)(bias[co] + sum_z partial[z][i]) for i over (B, Cout, npc)
 hipError_t launch_splitk_reduce(const float* partial, float* out, const float* bias, int ksplit, long long total,
                                 int Cout, int npc, int relu, hipStream_t s);

@@ -1,0 +1,303 @@
+// Layer-wise implicit-GEMM convolution with fp32-accurate products on the bf16 matrix cores ("bf16x6").
+//
+// Same contract, tensor layouts (fp32 (B, C, H, W) activations) and epilogue as conv_igemm_kernel in layerwise.hip
+// -- it is a drop-in replacement for the cases it supports: any conv with Cin > 1, and UNPADDED convs with Cin == 1
+// (every cnn-* conv_0 and every Linear).  See res8_bf16x6.hip for why: the fp32-input MFMA runs at 1/16 of the bf16
+// MFMA rate and blocks the VALU; six bf16 MFMA terms of three-way bf16 splits give the same (slightly better)
+// accuracy at 6/16 of the cost, and the VALU work of splitting co-executes with other waves' bf16 MFMAs.
+//
+//   * K is walked in blocks of 8: 8 consecutive input channels of one tap (Cin > 1), or 8 consecutive kernel columns of
+//     one kernel row (Cin == 1).  One v_mfma_f32_16x16x32_bf16 consumes 4 blocks (one per 16-lane group g), so k-step s
+//     covers blocks 4s..4s+3; lane group g decodes ITS block to (tap, channel block) / (row, column block).
+//   * A (weights): split into three bf16 parts on the host, fragment order [mgroup][k-step][MT][part][lane][8].
+//   * B (activations): each lane gathers its 8 fp32 values with 8 buffer loads at (per-block lane offset) + (scalar
+//     element stride); out-of-bounds taps carry an offset past the buffer and read 0.  The values are split into three
+//     bf16 parts in registers (44 VALU per fragment) right before use; the NEXT k-step's raw values and weights are
+//     requested before the current step's MFMAs.
+//   * per k-step and wave: MT x 4 tiles x 6 terms MFMAs.
+#include "kws_internal.h"
+
+#include <cstring>
+
+namespace kws {
+
+namespace {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int OOB = (int)0x80000000;
+
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ u32x4 bload4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float lo_f(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// 8 fp32 values -> three bf16x8 fragments (x = h + m + l to 24 bits)
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[3]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const unsigned h = pack2(a, b);
+        const float ra = a - lo_f(h), rb = b - hi_f(h);
+        const unsigned m = pack2(ra, rb);
+        const unsigned l = pack2(ra - lo_f(m), rb - hi_f(m));
+        out[0][i] = h;
+        out[1][i] = m;
+        out[2][i] = l;
+    }
+}
+
+#define XMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
+#define XMF6(A3, B3, C_)     \
+    XMF(A3[2], B3[0], C_);   \
+    XMF(A3[1], B3[1], C_);   \
+    XMF(A3[0], B3[2], C_);   \
+    XMF(A3[1], B3[0], C_);   \
+    XMF(A3[0], B3[1], C_);   \
+    XMF(A3[0], B3[0], C_);
+}  // namespace
+
+template <int MT, bool KX>
+__global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvArgs a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+    const int pcol = lane & 15;
+    const int npc = gm.Ho * gm.Wo;
+    const long long ntot = (long long)gm.B * npc;
+    const long long n0 = ((long long)blockIdx.x * 4 + w) * 64;
+    const int hw = gm.H * gm.W;
+
+    bool valid[4];
+    int iy0[4], ix0[4], inb[4], pos[4], bidx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long n = n0 + 16 * j + pcol;
+        valid[j] = n < ntot;
+        const long long nn = valid[j] ? n : ntot - 1;
+        const int b = (int)(nn / npc);
+        const int ps = (int)(nn - (long long)b * npc);
+        const int oy = ps / gm.Wo;
+        const int ox = ps - oy * gm.Wo;
+        bidx[j] = b;
+        pos[j] = ps;
+        iy0[j] = oy * gm.sh - gm.ph;
+        ix0[j] = ox * gm.sw - gm.pw;
+        inb[j] = b * gm.Cin * hw;
+    }
+
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((size_t)gm.B * gm.Cin * hw * 4), 0x00020000);
+    const int steps = gm.x_ksteps;
+    const int s_begin = gm.ksplit > 1 ? (int)blockIdx.z * gm.ksteps_split : 0;
+    const int s_end = gm.ksplit > 1 ? min(steps, s_begin + gm.ksteps_split) : steps;
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(a.apk16 + (size_t)blockIdx.y * steps * MT * 3 * 64 * 8), 0, steps * MT * 3 * 1024,
+        0x00020000);
+
+    // inner/outer split of the block index: blocks per "row" (tap for Cin > 1, kernel row for Cin == 1)
+    const int nbr = gm.x_blocks_per_row;
+    const int nblocks = gm.x_blocks;
+    const int estride = (KX ? gm.dw : hw) * 4;   // byte stride between the 8 elements of a block
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this lane group's block at k-step s: bi = 4 s + g -> (row r, block-in-row c)
+    auto block_voff = [&](int s, int (&voff)[4]) {
+        const int bi = 4 * s + g;
+        const int r = bi / nbr, c = bi - r * nbr;
+        const bool bok = bi < nblocks;
+        if (KX) {   // unpadded, Cin == 1: row = ky, block = 8 kernel columns
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                voff[j] = (valid[j] && bok) ? (inb[j] + (iy0[j] + r * gm.dh) * gm.W + ix0[j] + 8 * c * gm.dw) * 4 : OOB;
+        } else {    // row = tap (ky, kx), block = 8 input channels
+            const int ky = r / gm.kw, kx = r - ky * gm.kw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = iy0[j] + ky * gm.dh, ix = ix0[j] + kx * gm.dw;
+                const bool ok = valid[j] && bok && iy >= 0 && iy < gm.H && ix >= 0 && ix < gm.W;
+                voff[j] = ok ? (inb[j] + iy * gm.W + ix + 8 * c * hw) * 4 : OOB;
+            }
+        }
+    };
+
+    float raw0[4][8], raw1[4][8];
+
+    // raw fp32 B values of k-step S: requested one whole step ahead (they feed VALU work, which needs them early)
+#define XLOADB(RAW, S)                                                                                \
+    {                                                                                                 \
+        int voff_[4];                                                                                 \
+        block_voff(S, voff_);                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) RAW[j][e] = bload(rin, voff_[j], e * estride); \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+    // weights of k-step S are requested here: the split of the first tile (VALU) covers their L2 latency
+#define XCOMPUTE(RAW, S)                                                                              \
+    {                                                                                                 \
+        u32x4 wa_[MT][3];                                                                             \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                \
+            _Pragma("unroll") for (int pt = 0; pt < 3; ++pt)                                          \
+                wa_[m][pt] = bload4(rwt, lane * 16 + (m * 3 + pt) * 1024, (S) * MT * 3 * 1024);       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            u32x4 bs_[3];                                                                             \
+            split8(RAW[j], bs_);                                                                      \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) { XMF6(wa_[m], bs_, acc[m][j]) }           \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+
+    int s = s_begin;
+    XLOADB(raw0, s)
+    while (s + 2 < s_end) {
+        XLOADB(raw1, s + 1)
+        XCOMPUTE(raw0, s)
+        XLOADB(raw0, s + 2)
+        XCOMPUTE(raw1, s + 1)
+        s += 2;
+    }
+    if (s + 1 < s_end) {
+        XLOADB(raw1, s + 1)
+        XCOMPUTE(raw0, s)
+        XCOMPUTE(raw1, s + 1)
+    } else {
+        XCOMPUTE(raw0, s)
+    }
+#undef XLOADB
+#undef XCOMPUTE
+
+    int bmask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        bmask[j] = (iy0[j] >= 0 ? 1 : 0) | (iy0[j] + 2 * gm.dh < gm.H ? 2 : 0) | (ix0[j] >= 0 ? 4 : 0) |
+                   (ix0[j] + 2 * gm.dw < gm.W ? 8 : 0);
+
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = ((int)blockIdx.y * MT + m) * 16 + 4 * g + r;
+            if (co >= gm.Cout) continue;
+            const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!valid[j]) continue;
+                if (gm.ksplit > 1) {
+                    a.partial[((size_t)blockIdx.z * gm.B + bidx[j]) * gm.Cout * npc + (size_t)co * npc + pos[j]] = acc[m][j][r];
+                    continue;
+                }
+                float v = acc[m][j][r] + bias;
+                if (a.border) v += a.border[bmask[j] * gm.Cout + co];
+                if (gm.relu) v = fmaxf(v, 0.f);
+                const size_t idx = ((size_t)bidx[j] * gm.Cout + co) * npc + pos[j];
+                if (gm.accumulate) v += a.out[idx];
+                a.out[idx] = v;
+            }
+        }
+}
+
+template <int MT>
+static hipError_t launch_x_mt(const ConvGeom& g, const ConvArgs& a, hipStream_t s) {
+    const long long ntot = (long long)g.B * g.Ho * g.Wo;
+    dim3 grid((unsigned)((ntot + 255) / 256), (unsigned)((g.mtiles + MT - 1) / MT), (unsigned)(g.ksplit > 1 ? g.ksplit : 1));
+    if (g.kx_inner)
+        hipLaunchKernelGGL((conv_bf16x6_kernel<MT, true>), grid, dim3(256), 0, s, g, a);
+    else
+        hipLaunchKernelGGL((conv_bf16x6_kernel<MT, false>), grid, dim3(256), 0, s, g, a);
+    return hipGetLastError();
+}
+
+// Cin == 1: only unpadded convs whose 8-wide column blocks never run past a row of a caller-owned tensor
+// (kw % 8 == 0), or Linears (H == 1; their input is always a workspace buffer with slack behind it).
+bool conv_bf16x6_supported(const ConvGeom& g) {
+    if (!g.kx_inner) return true;
+    return g.ph == 0 && g.pw == 0 && g.dw == 1 && (g.kw % 8 == 0 || g.kh == 1);
+}
+
+hipError_t launch_conv_bf16x6(const ConvGeom& g, const ConvArgs& a, hipStream_t s) {
+    if (g.B <= 0) return hipSuccess;
+    switch (g.MT) {
+        case 1: return launch_x_mt<1>(g, a, s);
+        case 2: return launch_x_mt<2>(g, a, s);
+        case 3: return launch_x_mt<3>(g, a, s);
+        case 4: return launch_x_mt<4>(g, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------- host packing
+namespace {
+unsigned short bf16_rne_h(float x) {
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+float bf16_to_f_h(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+}  // namespace
+
+void conv_bf16x6_geometry(ConvGeom& g) {
+    if (g.kx_inner) {
+        g.x_blocks_per_row = (g.kw + 7) / 8;
+        g.x_blocks = g.kh * g.x_blocks_per_row;
+    } else {
+        g.x_blocks_per_row = (g.Cin + 7) / 8;
+        g.x_blocks = g.kh * g.kw * g.x_blocks_per_row;
+    }
+    g.x_ksteps = (g.x_blocks + 3) / 4;
+}
+
+// weights (Cout, Cin, kh, kw) -> [mgroup][k-step][MT][part][lane][8 bf16]; lane = (block slot g << 4) | row
+void pack_conv_weights_bf16x6(const ConvGeom& g, const float* w, std::vector<unsigned short>& dst) {
+    const int mgroups = (g.mtiles + g.MT - 1) / g.MT;
+    dst.assign((size_t)mgroups * g.x_ksteps * g.MT * 3 * 64 * 8, 0);
+    for (int mg = 0; mg < mgroups; ++mg)
+        for (int s = 0; s < g.x_ksteps; ++s)
+            for (int m = 0; m < g.MT; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = (mg * g.MT + m) * 16 + (lane & 15);
+                    const int bi = 4 * s + (lane >> 4);
+                    const int r = bi / g.x_blocks_per_row, cb = bi % g.x_blocks_per_row;
+                    for (int e = 0; e < 8; ++e) {
+                        float v = 0.f;
+                        if (bi < g.x_blocks && co < g.Cout) {
+                            if (g.kx_inner) {
+                                const int ky = r, kx = 8 * cb + e;
+                                if (kx < g.kw) v = w[((size_t)co * g.kh + ky) * g.kw + kx];
+                            } else {
+                                const int ky = r / g.kw, kx = r % g.kw, ci = 8 * cb + e;
+                                if (ci < g.Cin) v = w[(((size_t)co * g.Cin + ci) * g.kh + ky) * g.kw + kx];
+                            }
+                        }
+                        const unsigned short h = bf16_rne_h(v);
+                        const float r1 = v - bf16_to_f_h(h);
+                        const unsigned short mm = bf16_rne_h(r1);
+                        const unsigned short l = bf16_rne_h(r1 - bf16_to_f_h(mm));
+                        const unsigned short parts[3] = {h, mm, l};
+                        for (int pt = 0; pt < 3; ++pt)
+                            dst[(((((size_t)mg * g.x_ksteps + s) * g.MT + m) * 3 + pt) * 64 + lane) * 8 + e] = parts[pt];
+                    }
+                }
+}
+
+}  // namespace kws
