@@ -188,6 +188,26 @@ def main():
                    "weights_seed": 7, "result": res}, f, indent=1)
     print("evaluate:", how, res["loss"], res["metric_Acc"])
 
+    # ---- a checkpoint written by the reference's own Workspace._save (utils/workspace.py:34-45): res8_narrow
+    import tempfile
+    from utils import Workspace
+    tag, name, mcfg, full = [c for c in model_configs() if c[0] == "resnet__res8_narrow"][0]
+    sdn = weights.make_state_dict(name, mcfg, seed=7)
+    netn = find_cls(f"model.{name}")(dict(mcfg))
+    netn.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sdn.items()})
+    wrapped = torch.nn.DataParallel(netn)          # what run/train.py saves when num_gpu > 1: keys get a 'module.' prefix
+    opt = torch.optim.SGD(wrapped.parameters(), lr=0.1)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=3000)
+    with tempfile.TemporaryDirectory() as tmp:
+        ws = Workspace(torch.device("cpu"), os.path.join(tmp, "ws"), wrapped, find_cls("loss_fn.ce_loss"),
+                       {"Acc": find_cls("metric.Acc")(), "PerClassAcc": find_cls("metric.PerClassAcc")()}, opt, sched)
+        ws.save_best_model({"best_epoch": 3, "best_dev_criterion": 0.5, "best_dev_loss": 1.25})
+        with open(os.path.join(tmp, "ws", "best_model.pt"), "rb") as f:
+            blob = f.read()
+    with open(os.path.join(OUT, "checkpoint_res8_narrow_best_model.pt"), "wb") as f:
+        f.write(blob)
+    print("checkpoint fixture:", len(blob), "bytes")
+
     # ---- DCT pin (utils/audio_processor.py:27-29) with the installed scipy
     import scipy.fftpack
     rng = np.random.Generator(np.random.PCG64(5))

@@ -242,6 +242,38 @@ def test_evaluate_matches_reference_evaluate(torch_cuda):
     assert abs(res2["loss"] - res["loss"]) < 1e-5 and res2["metric_PerClassAcc"] == res["metric_PerClassAcc"]
 
 
+def test_entry_point_with_reference_checkpoint_and_odd_clip_length(torch_cuda, tmp_path):
+    torch = torch_cuda
+    import shutil
+    from honk2_amd.run.test import build_model, main
+    from honk2_amd.utils import load_checkpoint_state
+    from oracle import frontend, models
+    # evaluate_model_dir -> best_model.pt written by the reference's Workspace._save
+    cfg = json.load(open(os.path.join(os.path.dirname(GOLDEN), "configs", "res8_synthetic.json")))
+    cfg["model"]["config"] = {"pool": [4, 3], "n_feature_maps": 19, "n_layers": 6, "use_dilation": False}
+    cfg["SyntheticKWSDataset"]["num_samples"] = 64
+    shutil.copy(os.path.join(GOLDEN, "checkpoint_res8_narrow_best_model.pt"), tmp_path / "best_model.pt")
+    cfg["evaluate_model_dir"] = str(tmp_path)
+    res = main(cfg)
+    assert np.isfinite(res["loss"]) and 0.0 <= res["metric_Acc"] <= 1.0
+    # the weights that were evaluated are the checkpoint's: logits equal the reference golden for those weights
+    tag, name, mcfg, sd, feats, z = load_golden_model("model_resnet__res8_narrow.npz")
+    model = build_model(json.loads(json.dumps(cfg))).to("cuda:0").eval()
+    model.load_state_dict(load_checkpoint_state(str(tmp_path / "best_model.pt"))[0])
+    got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert np.abs(got - z["logits"]).max() < LOGIT_TOL
+    # res8 on clips that are not one second long: the fused kernel is specific to 101 frames, the layer-wise plan takes over
+    from oracle import weights
+    cfg8 = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 12}
+    sd8 = weights.make_state_dict("ResNet", cfg8, seed=7)
+    m8 = _build(torch, "ResNet", cfg8, sd8)
+    wav = weights.make_waveforms(5, n_samples=12000 + 77, seed=9)[2:]
+    y = m8.forward_wav(torch.from_numpy(wav).cuda()).cpu().numpy()
+    assert m8.plan_name() == "layerwise"
+    want = models.forward_numpy("ResNet", cfg8, sd8, frontend.compute_mfccs_batch(wav, "f64"), np.float64)
+    assert np.abs(y - want).max() < LOGIT_TOL and (y.argmax(1) == want.argmax(1)).all()
+
+
 def test_data_loader_and_entry_point(torch_cuda, tmp_path):
     torch = torch_cuda
     from honk2_amd.run.test import main
