@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkws_hip.so")
 
 KWS_MODEL_NONE, KWS_MODEL_RESNET, KWS_MODEL_CNN = 0, 1, 2
-KWS_DTYPE_F32 = 0
+KWS_DTYPE_F32, KWS_DTYPE_BF16X3 = 0, 1
+DTYPES = {"f32": KWS_DTYPE_F32, "fp32": KWS_DTYPE_F32, "float32": KWS_DTYPE_F32, "bf16x3": KWS_DTYPE_BF16X3}
 
 # every symbol include/kws.h declares (tests check the library exports exactly these)
 EXPORTS = (
@@ -108,7 +109,7 @@ def make_desc(family, n_labels=0, frontend=None, **kw):
     d = ModelDesc()
     d.struct_size = C.sizeof(ModelDesc)
     d.family = family
-    d.dtype = KWS_DTYPE_F32
+    d.dtype = DTYPES[str(kw.pop("dtype", "f32")).lower()]
     d.n_labels = n_labels
     fe = dict(FRONTEND_DEFAULTS)
     fe.update(frontend or {})

@@ -291,7 +291,9 @@ int upload_packed(ConvLayer& L, const float* w) {
 }
 
 // one conv launch through whichever kernel the layer supports (geometry fields B/H/W already set in g)
-int launch_layer(const ConvLayer& L, const ConvGeom& g, ConvArgs a, hipStream_t s) {
+int launch_layer(const ConvLayer& L, const ConvGeom& g_in, ConvArgs a, hipStream_t s, int terms = 6) {
+    ConvGeom g = g_in;
+    g.x_terms = terms;
     if (L.use_x) {
         a.apk16 = L.apk16.as<unsigned short>();
         HIP_TRY(launch_conv_bf16x6(g, a, s));
@@ -456,6 +458,7 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
     float* X = (float*)ws; ws += align256(small * cb * 4);
     float* Y = (float*)ws;
     const int C = sh.C;
+    const int terms = d.dtype == KWS_DTYPE_BF16X3 ? 3 : 6;
     int rc;
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
@@ -463,7 +466,7 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
         ConvGeom g0 = h->rconv[0].g;
         set_spatial(g0, nb, sh.T, sh.F);
         ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr, nullptr};
-        if ((rc = launch_layer(h->rconv[0], g0, a0, s))) return rc;
+        if ((rc = launch_layer(h->rconv[0], g0, a0, s, terms))) return rc;
         if (sh.pooled) HIP_TRY(launch_pool(bufA, X, nb * C, sh.T, sh.F, d.pool_h, d.pool_w, 0, s));
         // conv_i: odd i writes Y from X, even i accumulates into X from Y (prev_x lives in X)
         for (int i = 1; i <= d.n_layers; ++i) {
@@ -472,7 +475,7 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
             const bool even = (i % 2) == 0;
             ConvArgs a{even ? Y : X, even ? X : Y, h->rconv[i].apk.as<float>(), nullptr, nullptr, nullptr,
                        h->rconv[i].has_border ? h->rconv[i].border.as<float>() : nullptr};
-            if ((rc = launch_layer(h->rconv[i], g, a, s))) return rc;
+            if ((rc = launch_layer(h->rconv[i], g, a, s, terms))) return rc;
         }
         const float* fin = (d.n_layers % 2 == 0) ? X : Y;
         HIP_TRY(launch_mean_linear(fin, logits + (size_t)b0 * d.n_labels, nb, C, sh.H * sh.W,
@@ -483,7 +486,8 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
     return KWS_OK;
 }
 
-int launch_conv_auto(const ConvLayer& L, ConvGeom g, ConvArgs a, int nb, float* partial, size_t partial_bytes, hipStream_t s) {
+int launch_conv_auto(const ConvLayer& L, ConvGeom g, ConvArgs a, int nb, float* partial, size_t partial_bytes, hipStream_t s,
+                     int terms) {
     g.B = nb;
     const int steps = L.use_x ? g.x_ksteps : g.ksteps;
     g.ksplit = plan_ksplit(g, nb, steps);
@@ -494,14 +498,14 @@ int launch_conv_auto(const ConvLayer& L, ConvGeom g, ConvArgs a, int nb, float* 
         if (!partial || (size_t)g.ksplit * total * 4 > partial_bytes) g.ksplit = 1;   // no room: fall back to one pass
         else {
             a.partial = partial;
-            int rc = launch_layer(L, g, a, s);
+            int rc = launch_layer(L, g, a, s, terms);
             if (rc) return rc;
             HIP_TRY(launch_splitk_reduce(partial, a.out, a.bias, g.ksplit, total, g.Cout, g.Ho * g.Wo, g.relu, s));
             return KWS_OK;
         }
     }
     g.ksteps_split = steps;
-    return launch_layer(L, g, a, s);
+    return launch_layer(L, g, a, s, terms);
 }
 
 int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
@@ -511,6 +515,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
     float* P = (float*)ws;
     float* Q = (float*)(ws + align256(h->cnn_max_elems * cb * 4));
     float* part = (float*)(ws + 2 * align256(h->cnn_max_elems * cb * 4));
+    const int terms = d.dtype == KWS_DTYPE_BF16X3 ? 3 : 6;
     const size_t part_bytes = cnn_partial_bytes(h, cb);
     auto other = [&](const float* c) -> float* { return c == P ? Q : P; };
     for (int b0 = 0; b0 < B; b0 += cb) {
@@ -521,7 +526,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             g.B = nb;
             float* conv_out_buf = other(cur);
             ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), nullptr, h->cconv[i].bias.as<float>(), nullptr, nullptr};
-            int rcc = launch_layer(h->cconv[i], g, a, s);
+            int rcc = launch_layer(h->cconv[i], g, a, s, terms);
             if (rcc) return rcc;
             float* pooled = other(conv_out_buf);
             HIP_TRY(launch_pool(conv_out_buf, pooled, nb * g.Cout, g.Ho, g.Wo, d.pool_kh[i], d.pool_kw[i], 1, s));
@@ -533,7 +538,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             const bool last = i + 1 == h->clin.size();
             float* dst = last ? logits + (size_t)b0 * d.n_labels : other(cur);
             ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), nullptr, h->clin[i].bias.as<float>(), nullptr, nullptr};
-            int rc = launch_conv_auto(h->clin[i], g, a, nb, part, part_bytes, s);
+            int rc = launch_conv_auto(h->clin[i], g, a, nb, part, part_bytes, s, terms);
             if (rc) return rc;
             cur = dst;
         }
@@ -557,7 +562,8 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
             } else {
                 h->last_plan = "res8_fused";
                 Res8xParams p{feat, logits, h->r8_w0a.as<float>(), h->r8x_apk.p, h->r8_bn.as<float>(),
-                              h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq, h->d.n_labels, dbg};
+                              h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq, h->d.n_labels, dbg,
+                              h->d.dtype == KWS_DTYPE_BF16X3 ? 3 : 6};
                 HIP_TRY(launch_res8x(p, std::min(B, 256), s));
             }
         } else {
@@ -599,7 +605,8 @@ const char* kws_last_error(void) { return g_err.c_str(); }
 int kws_create(const kws_model_desc* desc, kws_handle** out) {
     if (!desc || !out) return fail(KWS_EINVAL, "null argument");
     if (desc->struct_size != (int)sizeof(kws_model_desc)) return fail(KWS_EINVAL, "kws_model_desc size mismatch (ABI)");
-    if (desc->dtype != KWS_DTYPE_F32) return fail(KWS_EUNSUPPORTED, "only KWS_DTYPE_F32 is implemented");
+    if (desc->dtype != KWS_DTYPE_F32 && desc->dtype != KWS_DTYPE_BF16X3)
+        return fail(KWS_EUNSUPPORTED, "dtype must be KWS_DTYPE_F32 or KWS_DTYPE_BF16X3");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return fail(KWS_EHIP, "no HIP device available: the HIP path is mandatory, there is no CPU fallback");

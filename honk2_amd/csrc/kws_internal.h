@@ -83,6 +83,7 @@ struct Res8xParams {
     const float* out_b;   // (n_labels)
     int B, T, F, n_labels;
     int debug;            // timing experiments only: 1 skip conv_0, 2 skip the MFMA loop
+    int terms;            // 6: fp32-accurate products; 3: KWS_DTYPE_BF16X3
 };
 size_t res8x_lds_bytes();
 hipError_t launch_res8x(const Res8xParams& p, int grid, hipStream_t s);
@@ -103,6 +104,7 @@ struct ConvGeom {
     int x_blocks_per_row;  // bf16x6 kernel: blocks of 8 per tap (ceil(Cin/8)) or per kernel row (ceil(kw/8))
     int x_blocks;          // total K blocks of 8
     int x_ksteps;          // ceil(x_blocks / 4): k-steps of v_mfma_f32_16x16x32_bf16
+    int x_terms;           // bf16 kernel: 6 (fp32-accurate) or 3 (KWS_DTYPE_BF16X3)
     int ksplit;            // > 1: K range split over blockIdx.z (flat Cin == 1 mode only); partial sums go to ConvArgs::partial
     int ksteps_split;      // k-steps per split
 };

@@ -57,16 +57,18 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[3]) {
 }
 
 #define XMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
-#define XMF6(A3, B3, C_)     \
-    XMF(A3[2], B3[0], C_);   \
-    XMF(A3[1], B3[1], C_);   \
-    XMF(A3[0], B3[2], C_);   \
-    XMF(A3[1], B3[0], C_);   \
-    XMF(A3[0], B3[1], C_);   \
+#define XMF6(A3, B3, C_)       \
+    if (TERMS == 6) {          \
+        XMF(A3[2], B3[0], C_); \
+        XMF(A3[1], B3[1], C_); \
+        XMF(A3[0], B3[2], C_); \
+    }                          \
+    XMF(A3[1], B3[0], C_);     \
+    XMF(A3[0], B3[1], C_);     \
     XMF(A3[0], B3[0], C_);
 }  // namespace
 
-template <int MT, bool KX>
+template <int MT, bool KX, int TERMS>
 __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -215,10 +217,17 @@ template <int MT>
 static hipError_t launch_x_mt(const ConvGeom& g, const ConvArgs& a, hipStream_t s) {
     const long long ntot = (long long)g.B * g.Ho * g.Wo;
     dim3 grid((unsigned)((ntot + 255) / 256), (unsigned)((g.mtiles + MT - 1) / MT), (unsigned)(g.ksplit > 1 ? g.ksplit : 1));
-    if (g.kx_inner)
-        hipLaunchKernelGGL((conv_bf16x6_kernel<MT, true>), grid, dim3(256), 0, s, g, a);
-    else
-        hipLaunchKernelGGL((conv_bf16x6_kernel<MT, false>), grid, dim3(256), 0, s, g, a);
+    if (g.x_terms == 3) {
+        if (g.kx_inner)
+            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, true, 3>), grid, dim3(256), 0, s, g, a);
+        else
+            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, false, 3>), grid, dim3(256), 0, s, g, a);
+    } else {
+        if (g.kx_inner)
+            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, true, 6>), grid, dim3(256), 0, s, g, a);
+        else
+            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, false, 6>), grid, dim3(256), 0, s, g, a);
+    }
     return hipGetLastError();
 }
 

@@ -74,9 +74,11 @@ __device__ __forceinline__ void store_split(char* lds, int addr, f32x4 v) {
 #define MF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
 // six-term product, small terms first
 #define MF6(A3, B_, C_)        \
-    MF(A3[2], B_[0], C_);      \
-    MF(A3[1], B_[1], C_);      \
-    MF(A3[0], B_[2], C_);      \
+    if (TERMS == 6) {          \
+        MF(A3[2], B_[0], C_);  \
+        MF(A3[1], B_[1], C_);  \
+        MF(A3[0], B_[2], C_);  \
+    }                          \
     MF(A3[1], B_[0], C_);      \
     MF(A3[0], B_[1], C_);      \
     MF(A3[0], B_[0], C_);
@@ -139,7 +141,7 @@ __device__ __forceinline__ void load_b(BFrag& b, const char* lds, int addr) {
         }                                                                             \
     }
 
-template <bool EVEN, bool LAST>
+template <int TERMS, bool EVEN, bool LAST>
 __device__ __forceinline__ void x_layer(const Res8xParams& p, const XCtx& c, int layer, int clip, f32x4 (&prev)[5][3],
                                         f32x4& prevx) {
     const int g = c.g, mx = c.mx;
@@ -244,6 +246,7 @@ __device__ __forceinline__ void x_layer(const Res8xParams& p, const XCtx& c, int
 
 size_t res8x_lds_bytes() { return (size_t)X_LDS_BYTES; }
 
+template <int TERMS>
 __global__ __launch_bounds__(256, 1) void res8x_kernel(Res8xParams p) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     XCtx c;
@@ -382,25 +385,31 @@ __global__ __launch_bounds__(256, 1) void res8x_kernel(Res8xParams p) {
         if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, prevx);
         __syncthreads();
 
-        x_layer<false, false>(p, c, 0, clip, prev, prevx);
-        x_layer<true, false>(p, c, 1, clip, prev, prevx);
-        x_layer<false, false>(p, c, 2, clip, prev, prevx);
-        x_layer<true, false>(p, c, 3, clip, prev, prevx);
-        x_layer<false, false>(p, c, 4, clip, prev, prevx);
-        x_layer<true, true>(p, c, 5, clip, prev, prevx);
+        x_layer<TERMS, false, false>(p, c, 0, clip, prev, prevx);
+        x_layer<TERMS, true, false>(p, c, 1, clip, prev, prevx);
+        x_layer<TERMS, false, false>(p, c, 2, clip, prev, prevx);
+        x_layer<TERMS, true, false>(p, c, 3, clip, prev, prevx);
+        x_layer<TERMS, false, false>(p, c, 4, clip, prev, prevx);
+        x_layer<TERMS, true, true>(p, c, 5, clip, prev, prevx);
     }
 }
 
 hipError_t launch_res8x(const Res8xParams& p, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)res8x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)res8x_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)res8x_lds_bytes());
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)res8x_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)res8x_lds_bytes());
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (p.B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(res8x_kernel, dim3((unsigned)grid), dim3(256), res8x_lds_bytes(), s, p);
+    if (p.terms == 3)
+        hipLaunchKernelGGL(res8x_kernel<3>, dim3((unsigned)grid), dim3(256), res8x_lds_bytes(), s, p);
+    else
+        hipLaunchKernelGGL(res8x_kernel<6>, dim3((unsigned)grid), dim3(256), res8x_lds_bytes(), s, p);
     return hipGetLastError();
 }
 

@@ -40,7 +40,8 @@ class CNN(BaseModel):
 
     def _make_desc(self):
         c = self.config
-        d = _lib.make_desc(_lib.KWS_MODEL_CNN, n_labels=c["n_labels"], time=c["time"], freq=c["frequency"])
+        d = _lib.make_desc(_lib.KWS_MODEL_CNN, n_labels=c["n_labels"], time=c["time"], freq=c["frequency"],
+                           dtype=c.get("dtype", "f32"))
         n = 0
         for i in (0, 1):
             if f"conv_{i}" not in c:

@@ -35,4 +35,4 @@ class ResNet(BaseModel):
         pool = c.get("pool", (0, 0))
         return _lib.make_desc(_lib.KWS_MODEL_RESNET, n_labels=c["n_labels"], n_layers=c["n_layers"],
                               n_feature_maps=c["n_feature_maps"], use_dilation=int(bool(c["use_dilation"])),
-                              pool_h=int(pool[0]), pool_w=int(pool[1]))
+                              pool_h=int(pool[0]), pool_w=int(pool[1]), dtype=c.get("dtype", "f32"))

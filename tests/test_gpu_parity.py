@@ -94,6 +94,26 @@ def test_model_logits_match_reference(torch_cuda, fname):
     assert model.plan_name() == ("res8_fused" if tag == "resnet__res8" else "layerwise")
 
 
+@pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_cnn__cnn-trad-pool2.npz", "model_resnet__res8.npz"])
+def test_reduced_precision_mode_bf16x3(torch_cuda, fname):
+    """Opt-in `dtype: "bf16x3"` (BASELINE configs[2]/[4] are reduced-precision cases): three-term bf16 products,
+    fp32 accumulation.  Tolerance as SURVEY.md Appendix C prescribes for fp16-class arithmetic (5e-3), argmax compared
+    only where the reference's top-1/top-2 margin exceeds twice the tolerance."""
+    torch = torch_cuda
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    model = _build(torch, name, dict(cfg, dtype="bf16x3"), sd)
+    got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
+    want = z["logits"]
+    tol = 5e-3
+    err = np.abs(got - want).max()
+    assert err < tol, (tag, err)
+    top = np.sort(want, axis=1)
+    clear = (top[:, -1] - top[:, -2]) > 2 * tol
+    assert (got.argmax(1) == want.argmax(1))[clear].all() and clear.any()
+    exact = _build(torch, name, cfg, sd)(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert np.abs(exact - want).max() <= err + 1e-6          # the default mode is at least as close to the reference
+
+
 def test_res8_fused_equals_layerwise_and_oracle_on_a_larger_batch(torch_cuda, monkeypatch):
     torch = torch_cuda
     from oracle import models, weights
