@@ -1,0 +1,429 @@
+// LDS-tiled 3x3 "same" convolution (any power-of-two dilation) over channels-last fp32 activations: the conv_i
+// layers of every ResNet that does not fit the fully fused res8 kernel (res15, res26, narrow variants, hey_snips).
+// Reference: model/resnet.py:24-31, 44-56 (Conv2d(C, C, 3, padding=d, dilation=d, bias=False) -> ReLU -> (+ prev_x on
+// even i) -> BatchNorm(affine=False)).
+//
+// The generic layer-wise kernels (layerwise*.hip) read every input value nine times (once per tap) from L2 and split
+// it into bf16 parts each time; they are bound by that traffic / VALU work, not by the matrix pipe.  Here a workgroup
+// copies the cells its 192 output positions need into LDS ONCE, splitting each fp32 value into its three bf16 parts
+// on the way in, and all nine taps are served from LDS as ready-made B fragments, as in the fused res8 kernel.
+//
+//   * Tensors are "CL": [cell][channel padded to 8] fp32 (C = 45 -> 192 B per cell), cells in "layout(d)":
+//         [clip][y mod d][x mod d][y / d][x / d]
+//     A conv with dilation d only couples positions with equal (y mod d, x mod d), so in layout(d) it is a DENSE 3x3 conv
+//     on d*d independent sub-maps of ceil(H/d) x ceil(W/d) cells: the halo of a tile is one row + one cell on each side
+//     whatever the dilation.  A layer writes the layout its consumer wants straight from its epilogue and reads the
+//     residual in the layout it was written in, so there is no reshuffling pass.  Sub-maps are padded to a common size;
+//     padded cells and cells past the tensor are replaced by zeros while staging; taps that leave the sub-map read a
+//     shared zero cell.
+//   * One workgroup = 192 consecutive positions of the flattened layout (12 position tiles, 3 per wave) plus a halo of
+//     Ws + 1 cells on each side; LDS cell = [part 0..2][channel] bf16 (288 B), <= 79 KB, two workgroups per CU, so one
+//     stages / stores while the other's waves keep the matrix pipe busy.  All of a thread's staging loads are in flight
+//     together; the residual is requested before the k-loop.
+//   * K order (tap, 8-channel block), 4 blocks per v_mfma_f32_16x16x32_bf16, six bf16 x bf16 terms per fp32-accurate
+//     product (res8_bf16x6.hip); weights pre-split on the host (pack_conv_weights_bf16x6) and read per wave from L2, one
+//     k-step ahead; B fragments are three ds_read_b128 per position tile, one tile ahead.
+//   * Epilogue: border bias (the previous BatchNorm's shift over the in-bounds taps, layerwise.hip), ReLU, residual,
+//     16-byte stores (4 channels) into layout(d_next).
+#include "kws_internal.h"
+
+namespace kws {
+
+namespace {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TILE_P = T3_TILE_P;   // output positions per workgroup
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float lo_f(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float hi_f(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ float relu1(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+// four fp32 values -> three parts of four bf16 each (x = h + m + l to 24 bits)
+__device__ __forceinline__ void split4(f32x4 x, u32x2 (&out)[3]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const unsigned h = pack2(a, b);
+        const float ra = a - lo_f(h), rb = b - hi_f(h);
+        const unsigned m = pack2(ra, rb);
+        const unsigned l = pack2(ra - lo_f(m), rb - hi_f(m));
+        out[0][i] = h;
+        out[1][i] = m;
+        out[2][i] = l;
+    }
+}
+
+// q / dv for 0 <= q < 2^24 with a precomputed reciprocal (exact after one correction step); rem receives q % dv
+__device__ __forceinline__ int fdiv(int q, int dv, float inv, int& rem) {
+    int t = (int)((float)q * inv);
+    int r = q - t * dv;
+    if (r < 0) {
+        --t;
+        r += dv;
+    } else if (r >= dv) {
+        ++t;
+        r -= dv;
+    }
+    rem = r;
+    return t;
+}
+
+// cell index of image position (b, y, x) in layout(2^ld) of an H x W map
+__device__ __forceinline__ int layout_cell(int b, int y, int x, int ld, int H, int W) {
+    const int d = 1 << ld, Hs = (H + d - 1) >> ld, Ws = (W + d - 1) >> ld;
+    const int sub = ((y & (d - 1)) << ld) | (x & (d - 1));
+    return (((b << (2 * ld)) + sub) * Hs + (y >> ld)) * Ws + (x >> ld);
+}
+
+#define TMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
+#define TMF6(A3, B3, C_)       \
+    if (TERMS == 6) {          \
+        TMF(A3[2], B3[0], C_); \
+        TMF(A3[1], B3[1], C_); \
+        TMF(A3[0], B3[2], C_); \
+    }                          \
+    TMF(A3[1], B3[0], C_);     \
+    TMF(A3[0], B3[1], C_);     \
+    TMF(A3[0], B3[0], C_);
+}  // namespace
+
+// NB: 8-channel blocks per cell (3: C <= 24, 6: C <= 48); MT: 16-channel output tiles (2 / 3)
+template <int NB, int MT, int TERMS>
+__global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) {
+    constexpr int CELL = NB * 48, PART = NB * 16;   // LDS cell: 3 parts x NB*8 channels x 2 B
+    constexpr int GCELL = NB * 32;                  // global cell: NB*8 channels x 4 B
+    constexpr int STEPS = (9 * NB + 3) / 4;
+    constexpr int NP = TERMS == 6 ? 3 : 2;
+    constexpr int NQ = NB * 2;         // 4-channel quads per cell
+    constexpr int NGRP = 256 / NQ;     // cells copied per pass (21 / 42)
+    constexpr int UNR = NB == 6 ? 7 : 4;   // passes in flight together
+    extern __shared__ __align__(16) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+    const int pcol = lane & 15;
+    const int ld = p.ld_in, d = 1 << ld, dmask = d - 1;
+    const int Hs = p.Hs, Ws = p.Ws;
+    const int P0 = (int)blockIdx.x * TILE_P;
+    const int ncell = TILE_P + 2 * Ws + 2;
+    const int zero_off = ncell * CELL;
+    const float inv_ws = 1.0f / (float)Ws, inv_hs = 1.0f / (float)Hs;
+
+    // ---------------------------------------------------------------- this lane's three output positions
+    int lbase[3], tmask[3], ob[3], oy[3], ox[3];
+    bool valid[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int local = (w * 3 + j) * 16 + pcol;
+        const int P = P0 + local;
+        int xs, ys;
+        const int t = fdiv(P, Ws, inv_ws, xs);
+        const int m = fdiv(t, Hs, inv_hs, ys);
+        const int sub = m & (d * d - 1);
+        ob[j] = m >> (2 * ld);
+        oy[j] = (ys << ld) + (sub >> ld);
+        ox[j] = (xs << ld) + (sub & dmask);
+        valid[j] = P < p.total && oy[j] < p.H && ox[j] < p.W;
+        int mk = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = ys + ky - 1, xx = xs + kx - 1;
+                if (yy >= 0 && yy < Hs && xx >= 0 && xx < Ws) mk |= 1 << (ky * 3 + kx);
+            }
+        tmask[j] = mk;
+        lbase[j] = (local + Ws + 1) * CELL;
+    }
+
+    // residual values of this lane's outputs: requested now, consumed in the epilogue
+    f32x4 resv[3][MT];
+    const char* const resp = reinterpret_cast<const char*>(p.res);
+    if (resp) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const size_t rcell = (size_t)layout_cell(ob[j], oy[j], ox[j], p.ld_res, p.H, p.W) * GCELL;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = m * 16 + 4 * g;
+                resv[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (valid[j] && co0 < NB * 8) resv[j][m] = *reinterpret_cast<const f32x4*>(resp + rcell + co0 * 4);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- stage cells [P0 - Ws - 1, P0 + TILE_P + Ws + 1)
+    {
+        const int qd = tid % NQ, grp = tid / NQ;
+        if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + zero_off + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+        if (grp < NGRP) {
+            const char* src = reinterpret_cast<const char*>(p.in);
+            for (int i0 = grp; i0 < ncell; i0 += UNR * NGRP) {
+                f32x4 v[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int i = i0 + u * NGRP;
+                    const int q = P0 - Ws - 1 + i;   // global cell
+                    const int qq = q < 0 ? 0 : q;
+                    int xs, ys;
+                    const int t = fdiv(qq, Ws, inv_ws, xs);
+                    const int m = fdiv(t, Hs, inv_hs, ys);
+                    const int sub = m & (d * d - 1);
+                    const int yy = (ys << ld) + (sub >> ld), xx = (xs << ld) + (sub & dmask);
+                    const bool ok = i < ncell && q >= 0 && q < p.total && yy < p.H && xx < p.W;
+                    v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (ok) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)q * GCELL + qd * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int i = i0 + u * NGRP;
+                    if (i < ncell) {
+                        u32x2 pr[3];
+                        split4(v[u], pr);
+#pragma unroll
+                        for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const u32x4* A = reinterpret_cast<const u32x4*>(p.apk16) + lane;
+
+    f32x4 acc[3][MT];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this lane group's K block at k-step s: bi = 4 s + g -> (tap, channel block); returns the tap and the byte offset
+    // of (tap, block) relative to the centre cell
+    auto step_off = [&](int s, int& tap) {
+        const int bi = 4 * s + g;
+        tap = bi / NB;
+        const int cblk = bi - tap * NB;
+        const int ty = tap / 3, tx = tap - 3 * ty;
+        return ((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16;
+    };
+    auto b_addr = [&](int j, int tap, int off) {
+        return ((tmask[j] >> tap) & 1) ? lbase[j] + off : zero_off;   // tap >= 9 (zero-weight padding blocks): bit clear
+    };
+#define TLOADB(BR, ADDR)                                                                              \
+    {                                                                                                 \
+        const int ad_ = (ADDR);                                                                       \
+        _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) BR[pt] = *reinterpret_cast<const u32x4*>(lds + ad_ + pt * PART); \
+    }
+#define TLOADA(AR, S)                                                                                 \
+    {                                                                                                 \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                \
+            _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) AR[m][pt] = A[(((S) * MT + m) * 3 + pt) * 64]; \
+    }
+    // one k-step: B fragments are fetched one position tile ahead (tile 0 of the next step during tile 2); BX / BY are
+    // the two fragment buffers, BX holding tile 0 on entry and BY holding the next step's tile 0 on exit
+#define TSTEP(AR, BX, BY, OFFN, TAPN)                                                                 \
+    {                                                                                                 \
+        TLOADB(BY, b_addr(1, tap_c, off_c))                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], BX, acc[0][m]) }                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        TLOADB(BX, b_addr(2, tap_c, off_c))                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], BY, acc[1][m]) }                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        TLOADB(BY, b_addr(0, TAPN, OFFN))                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], BX, acc[2][m]) }                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+
+    u32x4 a0[MT][NP], a1[MT][NP], bb0[NP], bb1[NP];
+    int tap_c, off_c = step_off(0, tap_c);
+    TLOADA(a0, 0)
+    TLOADB(bb0, b_addr(0, tap_c, off_c))
+    for (int s = 0; s < STEPS; s += 2) {
+        int tap_n, off_n = step_off(s + 1, tap_n);
+        if (s + 1 < STEPS) TLOADA(a1, s + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        TSTEP(a0, bb0, bb1, off_n, tap_n)
+        if (s + 1 >= STEPS) break;
+        tap_c = tap_n;
+        off_c = off_n;
+        off_n = step_off(s + 2, tap_n);
+        if (s + 2 < STEPS) TLOADA(a0, s + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        TSTEP(a1, bb1, bb0, off_n, tap_n)
+        tap_c = tap_n;
+        off_c = off_n;
+    }
+#undef TLOADB
+#undef TLOADA
+#undef TSTEP
+
+    // ---------------------------------------------------------------- epilogue
+    char* const outp = reinterpret_cast<char*>(p.out);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (!valid[j]) continue;
+        const int bmask = (oy[j] - d >= 0 ? 1 : 0) | (oy[j] + d < p.H ? 2 : 0) | (ox[j] - d >= 0 ? 4 : 0) |
+                          (ox[j] + d < p.W ? 8 : 0);
+        const size_t ocell = (size_t)layout_cell(ob[j], oy[j], ox[j], p.ld_out, p.H, p.W) * GCELL;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co0 = m * 16 + 4 * g;
+            if (co0 >= NB * 8) continue;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool real = co0 + r < p.Cout;
+                float x = acc[j][m][r];
+                if (p.border && real) x += p.border[bmask * p.Cout + co0 + r];
+                x = relu1(x);
+                if (resp) x += resv[j][m][r];
+                v[r] = real ? x : 0.f;   // padded channels hold exact zeros
+            }
+            *reinterpret_cast<f32x4*>(outp + ocell + co0 * 4) = v;
+        }
+    }
+}
+
+size_t conv3x3_tile_lds_bytes(int cp, int Ws) { return (size_t)(T3_TILE_P + 2 * Ws + 3) * cp * 6; }
+
+bool conv3x3_tile_supported(int C, int Cout, int Ws) {
+    const int cp = (C + 7) / 8 * 8;
+    return C == Cout && (cp == 24 || cp == 48) && conv3x3_tile_lds_bytes(cp, Ws) <= 160 * 1024 - 512;
+}
+
+template <int NB, int MT>
+static hipError_t launch_t3(const TileConvParams& p, hipStream_t s) {
+    const unsigned grid = (unsigned)((p.total + T3_TILE_P - 1) / T3_TILE_P);
+    const size_t lds = conv3x3_tile_lds_bytes(NB * 8, p.Ws);
+    auto k6 = conv3x3_tile_kernel<NB, MT, 6>;
+    auto k3 = conv3x3_tile_kernel<NB, MT, 3>;
+    static bool attr_done = false;   // per instantiation: allow > 64 KB of dynamic LDS
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (p.terms == 3)
+        hipLaunchKernelGGL(k3, dim3(grid), dim3(256), lds, s, p);
+    else
+        hipLaunchKernelGGL(k6, dim3(grid), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s) {
+    if (p.total <= 0) return hipSuccess;
+    const int cp = (C + 7) / 8 * 8;
+    // positions are decoded with fp32 reciprocals (exact below 2^24) and byte offsets are 32-bit
+    if (!conv3x3_tile_supported(C, p.Cout, p.Ws) || (long long)p.total + T3_TILE_P + 2 * p.Ws + 2 >= (1 << 24) ||
+        (long long)p.total * cp * 4 >= (1LL << 31))
+        return hipErrorInvalidValue;
+    if (cp == 48) return launch_t3<6, 3>(p, s);
+    return launch_t3<3, 2>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 NCHW -> CL
+// (B, C, H, W) fp32 -> pooled (window kh x kw, stride = window, floor; mode 0 average, 1 max; 1 x 1 = plain transpose)
+// channels-last (B, H/kh, W/kw, cp) fp32, i.e. layout(1).  One thread: one output position x four channels.
+__global__ __launch_bounds__(256) void nchw_to_cl_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         long long total, int C, int H, int W, int Hp, int Wp, int kh,
+                                                         int kw, int is_max, int cp) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int nq = cp / 4;
+    const int ox = (int)(i % Wp);
+    long long t = i / Wp;
+    const int oy = (int)(t % Hp);
+    t /= Hp;
+    const int q = (int)(t % nq);
+    const long long b = t / nq;
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = 4 * q + r;
+        float x = 0.f;
+        if (c < C) {
+            const float* src = in + ((b * C + c) * H + (long long)oy * kh) * W + (long long)ox * kw;
+            x = is_max ? -INFINITY : 0.f;
+            for (int y = 0; y < kh; ++y)
+                for (int xx = 0; xx < kw; ++xx) {
+                    const float sv = src[y * W + xx];
+                    x = is_max ? fmaxf(x, sv) : x + sv;
+                }
+            if (!is_max) x = x / (float)(kh * kw);
+        }
+        v[r] = x;
+    }
+    *reinterpret_cast<f32x4*>(out + ((b * Hp + oy) * (long long)Wp + ox) * cp + q * 4) = v;
+}
+
+hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, int W, int kh, int kw, int is_max, int cp,
+                             hipStream_t s) {
+    const int Hp = H / kh, Wp = W / kw;
+    const long long total = (long long)B * (cp / 4) * Hp * Wp;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nchw_to_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, C, H, W,
+                       Hp, Wp, kh, kw, is_max, cp);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ mean + linear on CL
+// ResNet tail (reference model/resnet.py:57-59), last BatchNorm folded in: mean(BN(x)) == BN(mean(x)).
+// One workgroup per clip; x is (B, HW, cp) fp32 in layout(1).
+__global__ __launch_bounds__(256) void mean_linear_cl_kernel(const float* __restrict__ x, float* __restrict__ logits,
+                                                             int C, int cp, int HW, const float* mean, const float* rstd,
+                                                             const float* __restrict__ wt, const float* __restrict__ bias,
+                                                             int n_out) {
+    extern __shared__ float sm[];   // [nsl][cp] partial sums, then [cp] means
+    const int b = blockIdx.x;
+    const int nsl = 256 / cp > 0 ? 256 / cp : 1;   // cell slices summed in parallel
+    const int c = threadIdx.x % cp, sl = threadIdx.x / cp;
+    const float* base = x + (size_t)b * HW * cp;
+    if (sl < nsl) {
+        float s = 0.f;
+        for (int i = sl; i < HW; i += nsl) s += base[(size_t)i * cp + c];
+        sm[sl * cp + c] = s;
+    }
+    __syncthreads();
+    float* mv = sm + nsl * cp;
+    for (int cc = threadIdx.x; cc < C; cc += 256) {
+        float s = 0.f;
+        for (int k = 0; k < nsl; ++k) s += sm[k * cp + cc];
+        float m = s / (float)HW;
+        if (mean) m = (m - mean[cc]) * rstd[cc];
+        mv[cc] = m;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < n_out; o += 256) {
+        float v = 0.f;
+        for (int cc = 0; cc < C; ++cc) v = fmaf(wt[o * C + cc], mv[cc], v);
+        logits[(size_t)b * n_out + o] = v + bias[o];
+    }
+}
+
+hipError_t launch_mean_linear_cl(const float* x, float* logits, int B, int C, int cp, int HW, const float* mean,
+                                 const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (cp > 256) return hipErrorInvalidValue;
+    const int nsl = 256 / cp;
+    hipLaunchKernelGGL(mean_linear_cl_kernel, dim3((unsigned)B), dim3(256), (size_t)(nsl + 1) * cp * sizeof(float), s, x,
+                       logits, C, cp, HW, mean, rstd, w, bias, n_out);
+    return hipGetLastError();
+}
+
+}  // namespace kws

@@ -52,6 +52,10 @@ struct DevMem {
 };
 
 enum Plan { PLAN_FRONTEND_ONLY, PLAN_RESNET, PLAN_CNN };
+// layer-wise matrix path: fp32-input MFMA / bf16x6 over fp32 NCHW activations / the same plus the LDS-tiled 3x3 kernel
+// over channels-last activations for ResNets (default).  KWS_LAYERWISE_IMPL=fp32|nchw selects the first two (A/B
+// measurements, tests).
+enum LwMode { LW_FP32 = 0, LW_NCHW = 1, LW_TILED = 2 };
 
 struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the layer-wise plans
     ConvGeom g{};           // B/H/W/Ho/Wo filled per call for ResNet, at create for CNN
@@ -72,6 +76,7 @@ struct kws_handle {
     Plan plan = PLAN_FRONTEND_ONLY;
     bool res8_eligible = false;
     bool force_layerwise = false;
+    LwMode lw_mode = LW_TILED;
 
     // front end
     DevMem dft, hann, melw, mel_lo, mel_hi;
@@ -274,14 +279,13 @@ int build_cnn(kws_handle* h) {
     return KWS_OK;
 }
 
-int upload_packed(ConvLayer& L, const float* w) {
+int upload_packed(ConvLayer& L, const float* w, LwMode mode) {
     std::vector<float> pk;
     pack_conv_weights(L.g, w, pk);
     int rc = L.apk.upload(pk.data(), pk.size() * sizeof(float));
     if (rc) return rc;
     conv_bf16x6_geometry(L.g);
-    static const bool force_fp32 = std::getenv("KWS_LAYERWISE_IMPL") && std::strcmp(std::getenv("KWS_LAYERWISE_IMPL"), "fp32") == 0;
-    L.use_x = !force_fp32 && conv_bf16x6_supported(L.g);
+    L.use_x = mode != LW_FP32 && conv_bf16x6_supported(L.g);
     if (L.use_x) {
         std::vector<unsigned short> pk16;
         pack_conv_weights_bf16x6(L.g, w, pk16);
@@ -355,7 +359,7 @@ int finalize(kws_handle* h) {
                 if ((rc = L.border.upload(border.data(), border.size() * 4))) return rc;
                 L.has_border = true;
             }
-            if ((rc = upload_packed(L, wf.data()))) return rc;
+            if ((rc = upload_packed(L, wf.data(), h->lw_mode))) return rc;
         }
         if (h->res8_eligible) {
             std::vector<float> tab((size_t)R8_LAYERS * 96, 0.f);
@@ -395,6 +399,34 @@ ResnetShape resnet_shape(const kws_handle* h, int T) {
     return s;
 }
 
+int pad8(int c) { return (c + 7) / 8 * 8; }
+int ilog2(int d) { int l = 0; while ((1 << l) < d) ++l; return l; }
+
+// LDS-tiled 3x3 kernel usable for every conv_i of this ResNet?
+bool resnet_tiled(const kws_handle* h, const ResnetShape& s) {
+    return h->lw_mode == LW_TILED && conv3x3_tile_supported(s.C, s.C, s.W);
+}
+
+// cells per clip of the largest sub-map layout any layer uses (padding of the sub-maps included)
+size_t resnet_cl_cells(const kws_handle* h, const ResnetShape& s) {
+    size_t mx = (size_t)s.H * s.W;
+    for (int i = 1; i <= h->d.n_layers; ++i) {
+        const int d = resnet_dilation(h->d, i);
+        mx = std::max(mx, (size_t)d * d * ((s.H + d - 1) / d) * ((s.W + d - 1) / d));
+    }
+    return mx;
+}
+
+// clips per launch of the tiled plan: tensors under 1 GiB and under 2^24 cells (conv3x3_tile.hip decodes positions with
+// fp32 reciprocals)
+int chunk_clips(size_t per_clip_elems, int B);
+int tiled_chunk(const kws_handle* h, const ResnetShape& s, int B) {
+    const size_t cells = resnet_cl_cells(h, s);
+    const int cb = chunk_clips(std::max((size_t)s.C * s.T * s.F, cells * pad8(s.C)), B);
+    const size_t cap = (((size_t)1 << 24) - 4096) / cells;
+    return (int)std::max<size_t>(1, std::min<size_t>(cb, cap));
+}
+
 // clips per layer-wise launch: keep every activation tensor under 2^28 elements (1 GiB) and 32-bit indexable
 int chunk_clips(size_t per_clip_elems, int B) {
     size_t cb = ((size_t)1 << 28) / std::max<size_t>(per_clip_elems, 1);
@@ -425,6 +457,11 @@ size_t act_bytes(const kws_handle* h, int B, int T) {
         if (use_fused(h, T)) return 0;
         const ResnetShape s = resnet_shape(h, T);
         const size_t full = (size_t)s.C * s.T * s.F, small = (size_t)s.C * s.H * s.W;
+        if (resnet_tiled(h, s)) {   // conv_0 output (fp32 NCHW) + three channels-last tensors
+            const size_t cl = resnet_cl_cells(h, s) * pad8(s.C);
+            const int cb = tiled_chunk(h, s, B);
+            return align256(full * cb * 4) + 3 * align256(cl * cb * 4) + align256((size_t)8 * s.T * s.F * 4 + 4096);
+        }
         const int cb = chunk_clips(full, B);
         // + slack: padded channel blocks of the last clip read (and discard) up to 7 planes past a tensor's end
         return (s.pooled ? align256(full * cb * 4) : 0) + 2 * align256(small * cb * 4) + align256((size_t)8 * s.T * s.F * 4 + 4096);
@@ -447,10 +484,67 @@ int prof_mark(kws_handle* h, std::vector<hipEvent_t>& v, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------- model dispatch
+// ResNet, LDS-tiled plan: conv_0 (fp32 MFMA, NCHW out) -> pool / transpose to channels-last -> conv3x3_tile_kernel per
+// layer -> mean + Linear.  The residual stream alternates between two buffers because a layer reads prev_x in the
+// layout it was written in and writes the layout its consumer wants; odd layers write Y.
+int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
+    const kws_model_desc& d = h->d;
+    const ResnetShape sh = resnet_shape(h, T);
+    const int C = sh.C, cp = pad8(C);
+    const size_t full = (size_t)C * sh.T * sh.F, cl = resnet_cl_cells(h, sh) * cp;
+    const int cb = tiled_chunk(h, sh, B);
+    float* bufA = (float*)ws; ws += align256(full * cb * 4);
+    float* X = (float*)ws; ws += align256(cl * cb * 4);
+    float* X2 = (float*)ws; ws += align256(cl * cb * 4);
+    float* Y = (float*)ws;
+    const int terms = d.dtype == KWS_DTYPE_BF16X3 ? 3 : 6;
+    int rc;
+    for (int b0 = 0; b0 < B; b0 += cb) {
+        const int nb = std::min(cb, B - b0);
+        ConvGeom g0 = h->rconv[0].g;
+        set_spatial(g0, nb, sh.T, sh.F);
+        ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, bufA, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr, nullptr};
+        if ((rc = launch_layer(h->rconv[0], g0, a0, s, terms))) return rc;
+        HIP_TRY(launch_nchw_to_cl(bufA, X, nb, C, sh.T, sh.F, sh.pooled ? d.pool_h : 1, sh.pooled ? d.pool_w : 1, 0, cp, s));
+        float* xc = X;
+        float* xn = X2;
+        int ld_x = 0;   // layout of xc
+        for (int i = 1; i <= d.n_layers; ++i) {
+            const int ld_in = ilog2(resnet_dilation(d, i));
+            const int ld_out = i < d.n_layers ? ilog2(resnet_dilation(d, i + 1)) : 0;
+            const int dd = 1 << ld_in;
+            const bool even = (i % 2) == 0;
+            TileConvParams tp{};
+            tp.in = even ? Y : xc;
+            tp.out = even ? xn : Y;
+            tp.res = even ? xc : nullptr;
+            tp.apk16 = h->rconv[i].apk16.as<unsigned short>();
+            tp.border = h->rconv[i].has_border ? h->rconv[i].border.as<float>() : nullptr;
+            tp.B = nb; tp.H = sh.H; tp.W = sh.W; tp.Cout = C;
+            tp.ld_in = ld_in; tp.ld_out = ld_out; tp.ld_res = ld_x;
+            tp.Hs = (sh.H + dd - 1) / dd; tp.Ws = (sh.W + dd - 1) / dd;
+            tp.total = nb * dd * dd * tp.Hs * tp.Ws;
+            tp.terms = terms;
+            HIP_TRY(launch_conv3x3_tile(tp, C, s));
+            if (even) {
+                std::swap(xc, xn);
+                ld_x = ld_out;
+            }
+        }
+        const float* fin = (d.n_layers % 2 == 0) ? xc : Y;
+        HIP_TRY(launch_mean_linear_cl(fin, logits + (size_t)b0 * d.n_labels, nb, C, cp, sh.H * sh.W,
+                                      h->bn_mean.as<float>() + (size_t)(d.n_layers - 1) * C,
+                                      h->bn_rstd.as<float>() + (size_t)(d.n_layers - 1) * C, h->out_w.as<float>(),
+                                      h->out_b.as<float>(), d.n_labels, s));
+    }
+    return KWS_OK;
+}
+
 int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
     const kws_model_desc& d = h->d;
     const ResnetShape sh = resnet_shape(h, T);
     if (sh.H < 1 || sh.W < 1) return fail(KWS_EINVAL, "feature map smaller than the pooling window");
+    if (resnet_tiled(h, sh)) return run_resnet_tiled(h, feat, B, T, logits, ws, s);
     const size_t full = (size_t)sh.C * sh.T * sh.F, small = (size_t)sh.C * sh.H * sh.W;
     const int cb = chunk_clips(full, B);
     float* bufA = nullptr;
@@ -567,7 +661,7 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 HIP_TRY(launch_res8x(p, std::min(B, 256), s));
             }
         } else {
-            h->last_plan = "layerwise";
+            h->last_plan = resnet_tiled(h, resnet_shape(h, T)) ? "resnet_tiled" : "layerwise";
             if ((rc = run_resnet_layerwise(h, feat, B, T, logits, ws_act, s))) return rc;
         }
     } else if (h->plan == PLAN_CNN) {
@@ -616,6 +710,10 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
     HIP_TRY(hipGetDevice(&h->device));
     const char* fl = std::getenv("KWS_FORCE_LAYERWISE");
     h->force_layerwise = fl && fl[0] == '1';
+    if (const char* lw = std::getenv("KWS_LAYERWISE_IMPL")) {
+        if (std::strcmp(lw, "fp32") == 0) h->lw_mode = LW_FP32;
+        else if (std::strcmp(lw, "nchw") == 0) h->lw_mode = LW_NCHW;
+    }
     int rc = setup_frontend(h.get());
     if (rc) return rc;
     switch (desc->family) {
@@ -679,7 +777,7 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
             ConvLayer& L = h->cconv[idx];
             if (std::strcmp(field, "weight") == 0) {
                 if ((rc = need((size_t)L.g.Cout * L.g.Cin * L.g.kh * L.g.kw))) return rc;
-                if ((rc = upload_packed(L, src))) return rc;
+                if ((rc = upload_packed(L, src, h->lw_mode))) return rc;
             } else {
                 if ((rc = need(L.g.Cout))) return rc;
                 if ((rc = L.bias.upload(src, bytes))) return rc;
@@ -692,7 +790,7 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
             ConvLayer& L = h->clin[li];
             if (std::strcmp(field, "weight") == 0) {
                 if ((rc = need((size_t)L.g.Cout * L.g.kw))) return rc;
-                if ((rc = upload_packed(L, src))) return rc;
+                if ((rc = upload_packed(L, src, h->lw_mode))) return rc;
             } else {
                 if ((rc = need(L.g.Cout))) return rc;
                 if ((rc = L.bias.upload(src, bytes))) return rc;
@@ -719,6 +817,12 @@ int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes) {
     if (d_ptr && (reinterpret_cast<uintptr_t>(d_ptr) & 255)) return fail(KWS_EINVAL, "workspace must be 256-byte aligned");
     h->ws = d_ptr;
     h->ws_bytes = d_ptr ? bytes : 0;
+    // The generic layer-wise kernels read (and multiply by zero weights) up to 7 planes past the end of a tensor whose
+    // channel count is not a multiple of 8: make sure what they find there is finite from the first call on.
+    if (d_ptr && bytes) {
+        HIP_TRY(hipMemsetAsync(d_ptr, 0, bytes, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
     return KWS_OK;
 }
 

@@ -125,6 +125,28 @@ bool conv_bf16x6_supported(const ConvGeom& g);
 void conv_bf16x6_geometry(ConvGeom& g);
 hipError_t launch_conv_bf16x6(const ConvGeom& g, const ConvArgs& a, hipStream_t s);
 void pack_conv_weights_bf16x6(const ConvGeom& g, const float* w, std::vector<unsigned short>& dst);
+// LDS-tiled 3x3 "same" conv with power-of-two dilation over channels-last fp32 tensors in sub-map layouts
+// (conv3x3_tile.hip)
+constexpr int T3_TILE_P = 192;
+struct TileConvParams {
+    const float* in;       // CL tensor in layout(2^ld_in): [clip][y mod d][x mod d][ceil(H/d)][ceil(W/d)][cp] fp32
+    float* out;            // CL tensor, written in layout(2^ld_out)
+    const float* res;      // residual CL tensor in layout(2^ld_res), or nullptr
+    const unsigned short* apk16;   // pack_conv_weights_bf16x6 with MT = all channel tiles
+    const float* border;   // (16, Cout) or nullptr
+    int B, H, W, Cout;
+    int ld_in, ld_out, ld_res;
+    int Hs, Ws;            // ceil(H / d_in), ceil(W / d_in)
+    int total;             // B * d_in^2 * Hs * Ws cells of the input layout
+    int terms;
+};
+bool conv3x3_tile_supported(int C, int Cout, int Ws);
+hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
+// fp32 (B, C, H, W) -> pooled (stride = window, floor; 1 x 1 = transpose only) channels-last (B, H/kh, W/kw, cp) fp32
+hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, int W, int kh, int kw, int is_max, int cp,
+                             hipStream_t s);
+hipError_t launch_mean_linear_cl(const float* x, float* logits, int B, int C, int cp, int HW, const float* mean,
+                                 const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s);
 // out[i] = (relu?)(bias[co] + sum_z partial[z][i]) for i over (B, Cout, npc)
 hipError_t launch_splitk_reduce(const float* partial, float* out, const float* bias, int ksplit, long long total,
                                 int Cout, int npc, int relu, hipStream_t s);

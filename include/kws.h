@@ -98,7 +98,8 @@ void kws_destroy(kws_handle* h);
  * accepted and ignored.  Synchronous. */
 int kws_load_weights(kws_handle* h, const char* name, const void* host_ptr, size_t bytes);
 
-/* Device scratch the compute calls need for a batch of B clips whose feature maps have T frames. */
+/* Device scratch the compute calls need for a batch of B clips whose feature maps have T frames.
+ * kws_set_workspace zero-fills the block once (synchronous, on the null stream); the compute calls never do. */
 size_t kws_workspace_bytes(const kws_handle* h, int B, int T);
 int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes);
 

@@ -91,7 +91,7 @@ def test_model_logits_match_reference(torch_cuda, fname):
     assert np.abs(got - want).max() < LOGIT_TOL, (tag, np.abs(got - want).max())
     assert (got.argmax(1) == want.argmax(1)).all()
     assert model.num_params() == int(z["num_params"])
-    assert model.plan_name() == ("res8_fused" if tag == "resnet__res8" else "layerwise")
+    assert model.plan_name() == ("res8_fused" if tag == "resnet__res8" else "resnet_tiled" if name == "ResNet" else "layerwise")
 
 
 @pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_cnn__cnn-trad-pool2.npz", "model_resnet__res8.npz"])
@@ -127,13 +127,50 @@ def test_res8_fused_equals_layerwise_and_oracle_on_a_larger_batch(torch_cuda, mo
     monkeypatch.setenv("KWS_FORCE_LAYERWISE", "1")
     lw = _build(torch, "ResNet", cfg, sd)
     b = lw(x).cpu().numpy()
-    assert lw.plan_name() == "layerwise"
+    assert lw.plan_name() == "resnet_tiled"
     want = models.forward_torch("ResNet", cfg, sd, feats).numpy()
     assert np.abs(a - want).max() < LOGIT_TOL and np.abs(b - want).max() < LOGIT_TOL
     assert np.abs(a - b).max() < 1e-4
     margin = np.sort(want, axis=1)
     clear = (margin[:, -1] - margin[:, -2]) > 1e-4
     assert (a.argmax(1) == want.argmax(1))[clear].all() and clear.mean() > 0.9
+
+
+@pytest.mark.parametrize("impl", ["nchw", "fp32"])
+@pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_resnet__res26_narrow.npz", "model_cnn__cnn-tpool2.npz"])
+def test_alternative_layerwise_kernels_agree(torch_cuda, monkeypatch, fname, impl):
+    """KWS_LAYERWISE_IMPL selects the generic implicit-GEMM kernels (bf16x6 over NCHW / fp32-input MFMA) instead of the
+    LDS-tiled 3x3 kernel; all of them must meet the same bar."""
+    torch = torch_cuda
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    monkeypatch.setenv("KWS_LAYERWISE_IMPL", impl)
+    model = _build(torch, name, cfg, sd)
+    got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert model.plan_name() == "layerwise"
+    assert np.abs(got - z["logits"]).max() < LOGIT_TOL
+    assert (got.argmax(1) == z["logits"].argmax(1)).all()
+
+
+def test_tiled_resnet_on_odd_shapes_and_unsupported_widths(torch_cuda):
+    """The tiled 3x3 kernel on shapes no shipped config has: T not a multiple of anything, dilation reaching past the map,
+    batches that end inside a tile, pooling; and a channel count it does not cover (falls back to the generic kernels)."""
+    torch = torch_cuda
+    from oracle import models, weights
+    rng = np.random.default_rng(5)
+    for cfg, T, B, plan in [
+        ({"n_feature_maps": 45, "n_layers": 7, "use_dilation": True, "n_labels": 12}, 37, 3, "resnet_tiled"),
+        ({"n_feature_maps": 19, "n_layers": 13, "use_dilation": True, "n_labels": 5}, 23, 7, "resnet_tiled"),
+        ({"n_feature_maps": 42, "n_layers": 4, "use_dilation": False, "pool": [3, 2], "n_labels": 12}, 64, 2, "resnet_tiled"),
+        ({"n_feature_maps": 30, "n_layers": 5, "use_dilation": True, "n_labels": 12}, 50, 4, "layerwise"),
+    ]:
+        sd = weights.make_state_dict("ResNet", cfg, seed=21)
+        feats = (rng.standard_normal((B, T, 40)) * 2.5 + 0.65).astype(np.float32)
+        model = _build(torch, "ResNet", cfg, sd)
+        got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
+        assert model.plan_name() == plan, (cfg, model.plan_name())
+        want = models.forward_torch("ResNet", cfg, sd, feats).numpy()
+        assert np.abs(got - want).max() < LOGIT_TOL, (cfg, np.abs(got - want).max())
+        assert (got.argmax(1) == want.argmax(1)).all()
 
 
 def test_res8_fp32_mfma_kernel_agrees_with_bf16x6_kernel(torch_cuda, monkeypatch):
@@ -289,7 +326,7 @@ def test_entry_point_with_reference_checkpoint_and_odd_clip_length(torch_cuda, t
     m8 = _build(torch, "ResNet", cfg8, sd8)
     wav = weights.make_waveforms(5, n_samples=12000 + 77, seed=9)[2:]
     y = m8.forward_wav(torch.from_numpy(wav).cuda()).cpu().numpy()
-    assert m8.plan_name() == "layerwise"
+    assert m8.plan_name() == "resnet_tiled"
     want = models.forward_numpy("ResNet", cfg8, sd8, frontend.compute_mfccs_batch(wav, "f64"), np.float64)
     assert np.abs(y - want).max() < LOGIT_TOL and (y.argmax(1) == want.argmax(1)).all()
 
