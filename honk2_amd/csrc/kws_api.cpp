@@ -59,7 +59,7 @@ enum LwMode { LW_FP32 = 0, LW_NCHW = 1, LW_TILED = 2 };
 
 struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the layer-wise plans
     ConvGeom g{};           // B/H/W/Ho/Wo filled per call for ResNet, at create for CNN
-    DevMem apk, apk16, bias, border;
+    DevMem apk, apk16, bias, border, border_pad;   // border_pad: rows padded to a multiple of 8 channels (tiled kernel)
     bool has_bias = false, has_border = false, use_x = false;   // use_x: bf16x6 kernel available for this layer
     std::vector<float> w_host;   // ResNet: raw weights kept until finalize() folds the previous BatchNorm in
 };
@@ -73,6 +73,7 @@ struct BnHost {
 struct kws_handle {
     kws_model_desc d{};
     int device = 0;
+    int n_cu = 256;
     Plan plan = PLAN_FRONTEND_ONLY;
     bool res8_eligible = false;
     bool force_layerwise = false;
@@ -357,6 +358,11 @@ int finalize(kws_handle* h) {
                         for (int t9 = 0; t9 < 9; ++t9) wf[((size_t)co * C + ci) * 9 + t9] *= scp[ci];
                 }
                 if ((rc = L.border.upload(border.data(), border.size() * 4))) return rc;
+                const int cp = (C + 7) / 8 * 8;
+                std::vector<float> bpad((size_t)16 * cp, 0.f);
+                for (int mask = 0; mask < 16; ++mask)
+                    for (int co = 0; co < C; ++co) bpad[(size_t)mask * cp + co] = border[(size_t)mask * C + co];
+                if ((rc = L.border_pad.upload(bpad.data(), bpad.size() * 4))) return rc;
                 L.has_border = true;
             }
             if ((rc = upload_packed(L, wf.data(), h->lw_mode))) return rc;
@@ -423,7 +429,9 @@ int chunk_clips(size_t per_clip_elems, int B);
 int tiled_chunk(const kws_handle* h, const ResnetShape& s, int B) {
     const size_t cells = resnet_cl_cells(h, s);
     const int cb = chunk_clips(std::max((size_t)s.C * s.T * s.F, cells * pad8(s.C)), B);
-    const size_t cap = (((size_t)1 << 24) - 4096) / cells;
+    size_t cap = (((size_t)1 << 24) - 4096) / cells;
+    static const int env_cap = std::getenv("KWS_TILED_CHUNK") ? std::atoi(std::getenv("KWS_TILED_CHUNK")) : 0;   // experiments
+    if (env_cap > 0) cap = std::min<size_t>(cap, env_cap);
     return (int)std::max<size_t>(1, std::min<size_t>(cb, cap));
 }
 
@@ -519,12 +527,33 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
             tp.out = even ? xn : Y;
             tp.res = even ? xc : nullptr;
             tp.apk16 = h->rconv[i].apk16.as<unsigned short>();
-            tp.border = h->rconv[i].has_border ? h->rconv[i].border.as<float>() : nullptr;
+            tp.border = h->rconv[i].has_border ? h->rconv[i].border_pad.as<float>() : nullptr;
             tp.B = nb; tp.H = sh.H; tp.W = sh.W; tp.Cout = C;
             tp.ld_in = ld_in; tp.ld_out = ld_out; tp.ld_res = ld_x;
             tp.Hs = (sh.H + dd - 1) / dd; tp.Ws = (sh.W + dd - 1) / dd;
             tp.total = nb * dd * dd * tp.Hs * tp.Ws;
             tp.terms = terms;
+            tp.n_cu = h->n_cu;
+            static long long* t3prof = nullptr;
+            static const bool want_prof = std::getenv("KWS_T3_PROF") != nullptr;
+            if (want_prof && !t3prof) {
+                (void)hipMalloc((void**)&t3prof, 16 * sizeof(long long));
+                (void)hipMemset(t3prof, 0, 16 * sizeof(long long));
+            }
+            tp.prof = t3prof;
+            if (want_prof && i == d.n_layers && b0 + cb >= B) {   // dump and reset after the last launch of a forward
+                HIP_TRY(launch_conv3x3_tile(tp, C, s));
+                long long hp[16];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpy(hp, t3prof, sizeof(hp), hipMemcpyDeviceToHost);
+                (void)hipMemset(t3prof, 0, 16 * sizeof(long long));
+                std::fprintf(stderr, "T3PROF matrix: decode %lld barrier %lld loop %lld epilogue %lld | staging: work %lld barrier %lld tiles %lld\n",
+                             hp[0], hp[1], hp[2], hp[3], hp[8], hp[9], hp[10]);
+                if (even) { std::swap(xc, xn); ld_x = ld_out; }
+                continue;
+            }
+            static const int t3dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
+            tp.debug = t3dbg;
             HIP_TRY(launch_conv3x3_tile(tp, C, s));
             if (even) {
                 std::swap(xc, xn);
@@ -708,6 +737,7 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
     if (!h) return fail(KWS_ENOMEM, "out of host memory");
     h->d = *desc;
     HIP_TRY(hipGetDevice(&h->device));
+    HIP_TRY(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     const char* fl = std::getenv("KWS_FORCE_LAYERWISE");
     h->force_layerwise = fl && fl[0] == '1';
     if (const char* lw = std::getenv("KWS_LAYERWISE_IMPL")) {

@@ -133,12 +133,16 @@ struct TileConvParams {
     float* out;            // CL tensor, written in layout(2^ld_out)
     const float* res;      // residual CL tensor in layout(2^ld_res), or nullptr
     const unsigned short* apk16;   // pack_conv_weights_bf16x6 with MT = all channel tiles
-    const float* border;   // (16, Cout) or nullptr
+    const float* border;   // (16, C padded to 8) border-bias table, zeros in the padding, or nullptr
     int B, H, W, Cout;
     int ld_in, ld_out, ld_res;
     int Hs, Ws;            // ceil(H / d_in), ceil(W / d_in)
     int total;             // B * d_in^2 * Hs * Ws cells of the input layout
     int terms;
+    int n_cu;              // compute units of the device: the kernel is persistent, one workgroup per CU
+    long long* prof;       // KWS_T3_PROF: 16 device counters of in-kernel phase clocks (workgroup 0), or nullptr
+    int debug;             // KWS_T3_DEBUG, timing experiments only (results are wrong): 1 skip the k-loop, 2 skip the
+                           // staging loads, 4 skip the epilogue
 };
 bool conv3x3_tile_supported(int C, int Cout, int Ws);
 hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
