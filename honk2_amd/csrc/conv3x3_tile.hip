@@ -14,8 +14,8 @@
 //     on d*d independent sub-maps of ceil(H/d) x ceil(W/d) cells: the halo of a tile is one row + one cell on each side
 //     whatever the dilation.  A layer writes the layout its consumer wants straight from its epilogue and reads the
 //     residual in the layout it was written in, so there is no reshuffling pass.  Sub-maps are padded to a common size;
-//     padded cells and cells past the tensor are replaced by zeros while staging; taps that leave the sub-map read a
-//     shared zero cell.
+//     taps that leave the sub-map, land in its padding or outside the tensor read a shared zero cell (per-position tap
+//     mask), so what staging copies for such cells never matters.
 //   * One workgroup = 192 consecutive positions of the flattened layout (12 position tiles, 3 per wave) plus a halo of
 //     Ws + 1 cells on each side; LDS cell = [part 0..2][channel] bf16 (288 B), <= 79 KB, two workgroups per CU, so one
 //     stages / stores while the other's waves keep the matrix pipe busy.  All of a thread's staging loads are in flight
@@ -77,10 +77,6 @@ __device__ __forceinline__ int fdiv(int q, int dv, float inv, int& rem) {
     return t;
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, i.e. it would
-// make every tile wait for its own epilogue stores and for the weight loads already in flight for the next tile.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // cell index of image position (b, y, x) in layout(2^ld) of an H x W map
 __device__ __forceinline__ int layout_cell(int b, int y, int x, int ld, int H, int W) {
     const int d = 1 << ld, Hs = (H + d - 1) >> ld, Ws = (W + d - 1) >> ld;
@@ -101,15 +97,8 @@ __device__ __forceinline__ int layout_cell(int b, int y, int x, int ld, int H, i
 }  // namespace
 
 // NB: 8-channel blocks per cell (3: C <= 24, 6: C <= 48); MT: 16-channel output tiles (2 / 3)
-//
-// One persistent workgroup of 8 waves per CU, two roles, two LDS tile buffers:
-//   waves 0..3 ("matrix waves", one per SIMD): k-loop + epilogue of tile k from buffer k & 1;
-//   waves 4..7 ("staging waves", one per SIMD): copy + split tile k + 1 into buffer (k + 1) & 1 meanwhile.
-// One barrier per tile hands a filled buffer to the matrix waves and a drained one to the staging waves.  (Two
-// independent workgroups per CU run in lock-step -- both stage, then both share the matrix pipe -- and overlap nothing:
-// measured, the phases simply added up.)
 template <int NB, int MT, int TERMS>
-__global__ __launch_bounds__(512, 1) void conv3x3_tile_kernel(TileConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) {
     constexpr int CELL = NB * 48, PART = NB * 16;   // LDS cell: 3 parts x NB*8 channels x 2 B
     constexpr int GCELL = NB * 32;                  // global cell: NB*8 channels x 4 B
     constexpr int STEPS = (9 * NB + 3) / 4;
@@ -117,99 +106,119 @@ __global__ __launch_bounds__(512, 1) void conv3x3_tile_kernel(TileConvParams p) 
     constexpr int NQ = NB * 2;         // 4-channel quads per cell
     constexpr int NGRP = 256 / NQ;     // cells copied per pass (21 / 42)
     constexpr int UNR = NB == 6 ? 14 : 7;  // passes in flight together: a whole tile for W <= 40
-    extern __shared__ __align__(16) char lds_all[];
+    extern __shared__ __align__(16) char lds[];
 
-    const int tid = threadIdx.x & 255;
-    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
     const int pcol = lane & 15;
     const int ld = p.ld_in, d = 1 << ld, dmask = d - 1;
     const int Hs = p.Hs, Ws = p.Ws;
+    const int P0 = (int)blockIdx.x * TILE_P;
     const int ncell = TILE_P + 2 * Ws + 2;
     const int zero_off = ncell * CELL;
-    const int buf_bytes = (ncell + 1) * CELL;
-    const float* const bord = reinterpret_cast<const float*>(lds_all + 2 * buf_bytes);   // (16, NB*8) border-bias table
-    // (STEPS_E + 1, 4) x {byte offset of (tap, channel block) relative to the centre cell, 1 << tap (0 for padding blocks)}:
-    // lane group g's K block at k-step s is bi = 4 s + g -> tap = bi / NB, channel block bi % NB
-    constexpr int STEPS_E = STEPS + (STEPS & 1);
-    const u32x2* const steptab = reinterpret_cast<const u32x2*>(lds_all + 2 * buf_bytes + 16 * NB * 8 * 4);
     const float inv_ws = 1.0f / (float)Ws, inv_hs = 1.0f / (float)Hs;
-    const int ntiles = (p.total + TILE_P - 1) / TILE_P;
-    const int n_my = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
 
-    if (role == 1) {
-        // ------------------------------------------------------------ staging waves
+    // ---------------------------------------------------------------- this lane's three output positions
+    int lbase[3], tmask[3], ob[3], oy[3], ox[3];
+    bool valid[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int local = (w * 3 + j) * 16 + pcol;
+        const int P = P0 + local;
+        int xs, ys;
+        const int t = fdiv(P, Ws, inv_ws, xs);
+        const int m = fdiv(t, Hs, inv_hs, ys);
+        const int sub = m & (d * d - 1);
+        ob[j] = m >> (2 * ld);
+        oy[j] = (ys << ld) + (sub >> ld);
+        ox[j] = (xs << ld) + (sub & dmask);
+        valid[j] = P < p.total && oy[j] < p.H && ox[j] < p.W;
+        // a tap is live when it stays inside the sub-map AND lands on a real image position (sub-maps are padded to a
+        // common size; the padding and everything outside the tensor is never read as an operand)
+        const int r0 = sub >> ld, c0 = sub & dmask;
+        int rowok = 0, colok = 0;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const int yy = ys + kk - 1, xx = xs + kk - 1;
+            if (yy >= 0 && yy < Hs && (yy << ld) + r0 < p.H) rowok |= 1 << kk;
+            if (xx >= 0 && xx < Ws && (xx << ld) + c0 < p.W) colok |= 1 << kk;
+        }
+        int mk = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+            if ((rowok >> ky) & 1) mk |= colok << (3 * ky);
+        tmask[j] = mk;
+        lbase[j] = (local + Ws + 1) * CELL;
+    }
+
+    // residual values of this lane's outputs: requested now, consumed in the epilogue
+    f32x4 resv[3][MT];
+    const char* const resp = reinterpret_cast<const char*>(p.res);
+    if (resp) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const size_t rcell = (size_t)layout_cell(ob[j], oy[j], ox[j], p.ld_res, p.H, p.W) * GCELL;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = m * 16 + 4 * g;
+                resv[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (valid[j] && co0 < NB * 8) resv[j][m] = *reinterpret_cast<const f32x4*>(resp + rcell + co0 * 4);
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- stage cells [P0 - Ws - 1, P0 + TILE_P + Ws + 1)
+    {
         const int qd = tid % NQ, grp = tid / NQ;
-        if (tid < CELL / 16) {
-            *reinterpret_cast<u32x4*>(lds_all + zero_off + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4*>(lds_all + buf_bytes + zero_off + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
-        }
-        for (int i = tid; i < 16 * NB * 8; i += 256)
-            reinterpret_cast<float*>(lds_all + 2 * buf_bytes)[i] = p.border ? p.border[i] : 0.f;
-        if (tid < (STEPS_E + 1) * 4) {
-            const int bi = tid;   // = 4 s + g
-            const int tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
-            u32x2 e;
-            e[0] = (unsigned)(((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16);
-            e[1] = tap < 9 ? 1u << tap : 0u;
-            reinterpret_cast<u32x2*>(lds_all + 2 * buf_bytes + 16 * NB * 8 * 4)[tid] = e;
-        }
-        const char* src = reinterpret_cast<const char*>(p.in);
-        const bool prof = p.prof && blockIdx.x == 0 && tid == 0;
-        long long ps0 = 0, ps1 = 0, ps2 = 0;
-        for (int k = 0; k < n_my; ++k) {
-            const long long c0 = prof ? clock64() : 0;
-            char* lds = lds_all + (k & 1) * buf_bytes;
-            const int P0 = ((int)blockIdx.x + k * (int)gridDim.x) * TILE_P;
-            // cells [P0 - Ws - 1, P0 + TILE_P + Ws + 1): fp32 quads -> three bf16 parts; padded / outside cells -> zeros
-            if (grp < NGRP) {
-                for (int i0 = grp; i0 < ncell; i0 += UNR * NGRP) {
-                    f32x4 v[UNR];
+        if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + zero_off + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+        if (grp < NGRP) {
+            const char* src = reinterpret_cast<const char*>(p.in);
+            for (int i0 = grp; i0 < ncell; i0 += UNR * NGRP) {
+                f32x4 v[UNR];
 #pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        // Cells outside the tensor or in the padding of a sub-map are never tapped (tmask below), so
-                        // whatever is copied for them is irrelevant: clamp the address instead of testing.
-                        const int q = min(max(P0 - Ws - 1 + i0 + u * NGRP, 0), p.total - 1);
-                        v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (!(p.debug & 2)) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)q * GCELL + qd * 16);
-                    }
+                for (int u = 0; u < UNR; ++u) {
+                    // Cells outside the tensor or in the padding of a sub-map are never tapped (tmask above), so whatever
+                    // is copied for them is irrelevant: the address is clamped instead of tested.
+                    const int q = min(max(P0 - Ws - 1 + i0 + u * NGRP, 0), p.total - 1);
+                    v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)q * GCELL + qd * 16);
+                }
 #pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        const int i = i0 + u * NGRP;
-                        if (i < ncell && !(p.debug & 16)) {
-                            u32x2 pr[3];
-                            split4(v[u], pr);
+                for (int u = 0; u < UNR; ++u) {
+                    const int i = i0 + u * NGRP;
+                    if (i < ncell) {
+                        u32x2 pr[3];
+                        split4(v[u], pr);
 #pragma unroll
-                            for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
-                        }
+                        for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
                     }
                 }
             }
-            const long long c1 = prof ? clock64() : 0;
-            lds_barrier();   // buffer k & 1 is full; the matrix waves have drained buffer (k + 1) & 1
-            if (prof) {
-                const long long c2 = clock64();
-                ps0 += c1 - c0;
-                ps1 += c2 - c1;
-                ps2 += 1;
-            }
         }
-        if (prof) {
-            atomicAdd((unsigned long long*)p.prof + 8, (unsigned long long)ps0);
-            atomicAdd((unsigned long long*)p.prof + 9, (unsigned long long)ps1);
-            atomicAdd((unsigned long long*)p.prof + 10, (unsigned long long)ps2);
-        }
-        return;
     }
+    __syncthreads();
 
-    // ---------------------------------------------------------------- matrix waves
     const u32x4* A = reinterpret_cast<const u32x4*>(p.apk16) + lane;
-    const char* const resp = reinterpret_cast<const char*>(p.res);
-    char* const outp = reinterpret_cast<char*>(p.out);
 
+    f32x4 acc[3][MT];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // this lane group's K block at k-step s: bi = 4 s + g -> (tap, channel block); returns the tap and the byte offset
+    // of (tap, block) relative to the centre cell
+    auto step_off = [&](int s, int& tap) {
+        const int bi = 4 * s + g;
+        tap = bi / NB;
+        const int cblk = bi - tap * NB;
+        const int ty = tap / 3, tx = tap - 3 * ty;
+        return ((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16;
+    };
+    auto b_addr = [&](int j, int tap, int off) {
+        return ((tmask[j] >> tap) & 1) ? lbase[j] + off : zero_off;   // tap >= 9 (zero-weight padding blocks): bit clear
+    };
 #define TLOADB(BR, ADDR)                                                                              \
     {                                                                                                 \
         const int ad_ = (ADDR);                                                                       \
@@ -220,203 +229,82 @@ __global__ __launch_bounds__(512, 1) void conv3x3_tile_kernel(TileConvParams p) 
         _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                \
             _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) AR[m][pt] = A[(((S) * MT + m) * 3 + pt) * 64]; \
     }
-    u32x4 a0[MT][NP], a1[MT][NP];
-    if (n_my > 0) {
-        TLOADA(a0, 0)
-        TLOADA(a1, 1)
+    // one k-step: B fragments are fetched one position tile ahead (tile 0 of the next step during tile 2); BX / BY are
+    // the two fragment buffers, BX holding tile 0 on entry and BY holding the next step's tile 0 on exit
+#define TSTEP(AR, BX, BY, OFFN, TAPN)                                                                 \
+    {                                                                                                 \
+        TLOADB(BY, b_addr(1, tap_c, off_c))                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], BX, acc[0][m]) }                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        TLOADB(BX, b_addr(2, tap_c, off_c))                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], BY, acc[1][m]) }                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        TLOADB(BY, b_addr(0, TAPN, OFFN))                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], BX, acc[2][m]) }                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
     }
 
-    const bool prof = p.prof && blockIdx.x == 0 && tid == 0;
-    long long pm[4] = {0, 0, 0, 0};
-    for (int k = 0; k < n_my; ++k) {
-        const long long c0 = prof ? clock64() : 0;
-        const char* lds = lds_all + (k & 1) * buf_bytes;
-        const int P0 = ((int)blockIdx.x + k * (int)gridDim.x) * TILE_P;
-
-        // this lane's three output positions
-        int lbase[3], tmask[3], ob[3], oy[3], ox[3];
-        bool valid[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int local = (w * 3 + j) * 16 + pcol;
-            const int P = P0 + local;
-            int xs, ys;
-            const int t = fdiv(P, Ws, inv_ws, xs);
-            const int m = fdiv(t, Hs, inv_hs, ys);
-            const int sub = m & (d * d - 1);
-            ob[j] = m >> (2 * ld);
-            oy[j] = (ys << ld) + (sub >> ld);
-            ox[j] = (xs << ld) + (sub & dmask);
-            valid[j] = P < p.total && oy[j] < p.H && ox[j] < p.W;
-            // a tap is live when it stays inside the sub-map AND lands on a real image position (sub-maps are padded to a
-            // common size; the padding and everything outside the tensor is never read as an operand)
-            const int r0 = sub >> ld, c0 = sub & dmask;
-            int rowok = 0, colok = 0;
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const int yy = ys + kk - 1, xx = xs + kk - 1;
-                if (yy >= 0 && yy < Hs && (yy << ld) + r0 < p.H) rowok |= 1 << kk;
-                if (xx >= 0 && xx < Ws && (xx << ld) + c0 < p.W) colok |= 1 << kk;
-            }
-            int mk = 0;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-                if ((rowok >> ky) & 1) mk |= colok << (3 * ky);
-            tmask[j] = mk;
-            lbase[j] = (local + Ws + 1) * CELL;
-        }
-
-        // residual and border bias of this lane's outputs: requested now, consumed in the epilogue
-        f32x4 resv[3][MT];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int bmask = (oy[j] - d >= 0 ? 1 : 0) | (oy[j] + d < p.H ? 2 : 0) | (ox[j] - d >= 0 ? 4 : 0) |
-                              (ox[j] + d < p.W ? 8 : 0);
-            const size_t rcell = resp ? (size_t)layout_cell(ob[j], oy[j], ox[j], p.ld_res, p.H, p.W) * GCELL : 0;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int co0 = m * 16 + 4 * g;
-                resv[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (valid[j] && co0 < NB * 8) {
-                    if (resp) resv[j][m] = *reinterpret_cast<const f32x4*>(resp + rcell + co0 * 4);
-                    (void)bmask;
-                }
-            }
-        }
-
-        f32x4 acc[3][MT];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        auto b_addr = [&](int j, unsigned tapbit, int off) {
-            return (tmask[j] & tapbit) ? lbase[j] + off : zero_off;   // padding blocks have no tap bit
-        };
-    // One k-step.  A wave has no MFMA queue: whatever it issues between two MFMAs is a bubble in the matrix pipe unless it
-    // fits in the ~12 issue cycles a 16-cycle MFMA leaves free.  So the step's other work is hooked in BETWEEN the MFMAs
-    // of the accumulation chains and pinned there (sched_barrier after every unit):
-    //   chain of channel tile 0 : address + three ds_read_b128 of the NEXT position tile's B fragment
-    //   chains of tiles 1.. (last position tile of the step only): reload the weight fragments whose last use has passed
-    //   (channel tile m - 1) with step s + 2; the last channel tile's reload follows the step.
-    // BX / BY are the two B buffers: BX holds position tile 0 on entry, BY the next step's tile 0 on exit.
-#define SB __builtin_amdgcn_sched_barrier(0)
-#define LDSV(AD_) (*reinterpret_cast<const u32x4*>(lds + (AD_)))
-    // one term of the product for every channel tile: MT independent MFMAs (dependent MFMAs issue at half rate, so a
-    // chain on ONE accumulator must never run back to back), a hook after each
-#define TROW(AR, BC, J, PA, PB, H0, H1, H2)                                           \
-    TMF(AR[0][PA], BC[PB], acc[J][0]); SB; H0; SB;                                    \
-    TMF(AR[1][PA], BC[PB], acc[J][1]); SB; H1; SB;                                    \
-    if (MT > 2) { TMF(AR[MT - 1][PA], BC[PB], acc[J][MT - 1]); SB; }                  \
-    H2; SB;
-#define ALD(AR, M_, PT_, SN, DOA) \
-    if ((DOA) && (M_) < MT) AR[(M_) < MT ? (M_) : 0][PT_] = A[(((SN) * MT + (M_)) * 3 + (PT_)) * 64]
-    // terms, small first: a3b1 a2b2 a1b3 a2b1 a1b2 a1b1 (parts are indexed from 0).  A part's registers are free for
-    // the reload as soon as its last term has been issued: part 2 after the first row, part 1 after the fourth.
-#define TTILE(J, AR, BC, BN, HA, HB, SN, DOA)                                                                    \
-    if (TERMS == 6) {                                                                                            \
-        TROW(AR, BC, J, NP - 1, 0, BN[0] = LDSV(nad), BN[1] = LDSV(nad + PART), BN[NP - 1] = LDSV(nad + 2 * PART)) \
-        TROW(AR, BC, J, 1, 1, ALD(AR, 0, NP - 1, SN, DOA), ALD(AR, 1, NP - 1, SN, DOA), ALD(AR, 2, NP - 1, SN, DOA)) \
-        TROW(AR, BC, J, 0, NP - 1, HA, HB, (void)0)                                                              \
-        TROW(AR, BC, J, 1, 0, (void)0, (void)0, (void)0)                                                         \
-        TROW(AR, BC, J, 0, 1, ALD(AR, 0, 1, SN, DOA), ALD(AR, 1, 1, SN, DOA), ALD(AR, 2, 1, SN, DOA))            \
-        TROW(AR, BC, J, 0, 0, (void)0, (void)0, (void)0)                                                         \
-    } else {                                                                                                     \
-        TROW(AR, BC, J, 1, 0, BN[0] = LDSV(nad), BN[1] = LDSV(nad + PART), (void)0)                              \
-        TROW(AR, BC, J, 0, 1, ALD(AR, 0, 1, SN, DOA), ALD(AR, 1, 1, SN, DOA), ALD(AR, 2, 1, SN, DOA))            \
-        TROW(AR, BC, J, 0, 0, HA, HB, (void)0)                                                                   \
-    }                                                                                                            \
-    ALD(AR, 0, 0, SN, DOA); ALD(AR, 1, 0, SN, DOA); ALD(AR, 2, 0, SN, DOA); SB;
-    // `nad` is the LDS address of the B fragment to prefetch next (always one position tile ahead); it is computed one
-    // tile before it is used: during tile 0 for tile 2, during tile 1 for the next step's tile 0 (step table entry
-    // requested in the same tile), during tile 2 for the next step's tile 1.
-#define TSTEP(AR, BX, BY, SNEXT, SN)                                                                             \
-    {                                                                                                            \
-        u32x2 st_;                                                                                               \
-        TTILE(0, AR, BX, BY, nad = b_addr(2, st_c[1], (int)st_c[0]), st_ = steptab[(SNEXT) * 4 + g], SN, false)  \
-        TTILE(1, AR, BY, BX, nad = b_addr(0, st_[1], (int)st_[0]), (void)0, SN, false)                           \
-        TTILE(2, AR, BX, BY, nad = b_addr(1, st_[1], (int)st_[0]), (void)0, SN, !(p.debug & 8))                  \
-        st_c = st_;                                                                                              \
+    u32x4 a0[MT][NP], a1[MT][NP], bb0[NP], bb1[NP];
+    int tap_c, off_c = step_off(0, tap_c);
+    TLOADA(a0, 0)
+    TLOADB(bb0, b_addr(0, tap_c, off_c))
+    for (int s = 0; s < STEPS; s += 2) {
+        int tap_n, off_n = step_off(s + 1, tap_n);
+        if (s + 1 < STEPS) TLOADA(a1, s + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        TSTEP(a0, bb0, bb1, off_n, tap_n)
+        if (s + 1 >= STEPS) break;
+        tap_c = tap_n;
+        off_c = off_n;
+        off_n = step_off(s + 2, tap_n);
+        if (s + 2 < STEPS) TLOADA(a0, s + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        TSTEP(a1, bb1, bb0, off_n, tap_n)
+        tap_c = tap_n;
+        off_c = off_n;
     }
-
-        // The weight fragments form one continuous stream over the tiles: a0 / a1 hold steps s / s + 1, and a step's
-        // buffer is reloaded with step s + 2 while its last MFMAs are issued -- wrapping to the NEXT tile's steps 0 / 1
-        // at the end, so those loads are older than this tile's epilogue stores (loads and stores retire in order: a
-        // wait on a younger load would also wait for the stores).  An odd step count is padded with a skipped step.
-        u32x4 bb0[NP], bb1[NP];
-        const long long c1 = prof ? clock64() : 0;
-        lds_barrier();   // tile k is in buffer k & 1
-        const long long c2 = prof ? clock64() : 0;
-        u32x2 st_c = steptab[g];
-        TLOADB(bb0, b_addr(0, st_c[1], (int)st_c[0]))
-        int nad = b_addr(1, st_c[1], (int)st_c[0]);
-#pragma unroll 1
-        for (int s = (p.debug & 1) ? STEPS_E : 0; s < STEPS_E; s += 2) {
-            TSTEP(a0, bb0, bb1, s + 1, (s + 2 == STEPS_E ? 0 : s + 2))
-            if ((STEPS & 1) == 0 || s + 1 < STEPS) {
-                TSTEP(a1, bb1, bb0, s + 2, (s + 3 >= STEPS_E ? s + 3 - STEPS_E : s + 3))
-            } else {
-                TLOADA(a1, 1)   // skipped padding step: its buffer still has to receive the next tile's step 1
-                SB;
-            }
-        }
-
-        const long long c3 = prof ? clock64() : 0;
-        // epilogue
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (!valid[j] || (p.debug & 4)) continue;
-            const int bmask = (oy[j] - d >= 0 ? 1 : 0) | (oy[j] + d < p.H ? 2 : 0) | (ox[j] - d >= 0 ? 4 : 0) |
-                              (ox[j] + d < p.W ? 8 : 0);
-            const size_t ocell = (size_t)layout_cell(ob[j], oy[j], ox[j], p.ld_out, p.H, p.W) * GCELL;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int co0 = m * 16 + 4 * g;
-                if (co0 >= NB * 8) continue;
-                f32x4 v;
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(bord + bmask * (NB * 8) + co0);   // rows padded to NB*8, zeros past Cout
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = relu1(acc[j][m][r] + bb[r]);
-                    if (resp) x += resv[j][m][r];
-                    v[r] = co0 + r < p.Cout ? x : 0.f;   // padded channels hold exact zeros
-                }
-                *reinterpret_cast<f32x4*>(outp + ocell + co0 * 4) = v;
-            }
-        }
-        if (prof) {
-            const long long c4 = clock64();
-            pm[0] += c1 - c0;
-            pm[1] += c2 - c1;
-            pm[2] += c3 - c2;
-            pm[3] += c4 - c3;
-        }
-    }
-    if (prof)
-        for (int i = 0; i < 4; ++i) atomicAdd((unsigned long long*)p.prof + i, (unsigned long long)pm[i]);
 #undef TLOADB
 #undef TLOADA
 #undef TSTEP
-#undef TTILE
-#undef TROW
-#undef ALD
-#undef LDSV
-#undef SB
+
+    // ---------------------------------------------------------------- epilogue
+    char* const outp = reinterpret_cast<char*>(p.out);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (!valid[j]) continue;
+        const int bmask = (oy[j] - d >= 0 ? 1 : 0) | (oy[j] + d < p.H ? 2 : 0) | (ox[j] - d >= 0 ? 4 : 0) |
+                          (ox[j] + d < p.W ? 8 : 0);
+        const size_t ocell = (size_t)layout_cell(ob[j], oy[j], ox[j], p.ld_out, p.H, p.W) * GCELL;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co0 = m * 16 + 4 * g;
+            if (co0 >= NB * 8) continue;
+            f32x4 v, bb = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.border) bb = *reinterpret_cast<const f32x4*>(p.border + bmask * (NB * 8) + co0);   // rows padded to NB*8, zeros past Cout
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = relu1(acc[j][m][r] + bb[r]);
+                if (resp) x += resv[j][m][r];
+                v[r] = co0 + r < p.Cout ? x : 0.f;   // padded channels hold exact zeros
+            }
+            *reinterpret_cast<f32x4*>(outp + ocell + co0 * 4) = v;
+        }
+    }
 }
 
-// two tile buffers, each (TILE_P + 2 Ws + 2) cells + one zero cell
-// + border-bias table + k-step table
-size_t conv3x3_tile_lds_bytes(int cp, int Ws) { return (size_t)2 * (T3_TILE_P + 2 * Ws + 3) * cp * 6 + (size_t)16 * cp * 4 + 16 * 4 * 8; }
+size_t conv3x3_tile_lds_bytes(int cp, int Ws) { return (size_t)(T3_TILE_P + 2 * Ws + 3) * cp * 6; }
 
 bool conv3x3_tile_supported(int C, int Cout, int Ws) {
     const int cp = (C + 7) / 8 * 8;
-    return C == Cout && (cp == 24 || cp == 48) && conv3x3_tile_lds_bytes(cp, Ws) <= 160 * 1024;
+    return C == Cout && (cp == 24 || cp == 48) && conv3x3_tile_lds_bytes(cp, Ws) <= 160 * 1024 - 512;
 }
 
 template <int NB, int MT>
 static hipError_t launch_t3(const TileConvParams& p, hipStream_t s) {
-    const unsigned ntiles = (unsigned)((p.total + T3_TILE_P - 1) / T3_TILE_P);
-    const unsigned grid = ntiles < (unsigned)p.n_cu ? ntiles : (unsigned)p.n_cu;   // one persistent workgroup per CU
+    const unsigned grid = (unsigned)((p.total + T3_TILE_P - 1) / T3_TILE_P);
     const size_t lds = conv3x3_tile_lds_bytes(NB * 8, p.Ws);
     auto k6 = conv3x3_tile_kernel<NB, MT, 6>;
     auto k3 = conv3x3_tile_kernel<NB, MT, 3>;
@@ -429,9 +317,9 @@ static hipError_t launch_t3(const TileConvParams& p, hipStream_t s) {
         attr_done = true;
     }
     if (p.terms == 3)
-        hipLaunchKernelGGL(k3, dim3(grid), dim3(512), lds, s, p);
+        hipLaunchKernelGGL(k3, dim3(grid), dim3(256), lds, s, p);
     else
-        hipLaunchKernelGGL(k6, dim3(grid), dim3(512), lds, s, p);
+        hipLaunchKernelGGL(k6, dim3(grid), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 

@@ -533,27 +533,6 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
             tp.Hs = (sh.H + dd - 1) / dd; tp.Ws = (sh.W + dd - 1) / dd;
             tp.total = nb * dd * dd * tp.Hs * tp.Ws;
             tp.terms = terms;
-            tp.n_cu = h->n_cu;
-            static long long* t3prof = nullptr;
-            static const bool want_prof = std::getenv("KWS_T3_PROF") != nullptr;
-            if (want_prof && !t3prof) {
-                (void)hipMalloc((void**)&t3prof, 16 * sizeof(long long));
-                (void)hipMemset(t3prof, 0, 16 * sizeof(long long));
-            }
-            tp.prof = t3prof;
-            if (want_prof && i == d.n_layers && b0 + cb >= B) {   // dump and reset after the last launch of a forward
-                HIP_TRY(launch_conv3x3_tile(tp, C, s));
-                long long hp[16];
-                (void)hipDeviceSynchronize();
-                (void)hipMemcpy(hp, t3prof, sizeof(hp), hipMemcpyDeviceToHost);
-                (void)hipMemset(t3prof, 0, 16 * sizeof(long long));
-                std::fprintf(stderr, "T3PROF matrix: decode %lld barrier %lld loop %lld epilogue %lld | staging: work %lld barrier %lld tiles %lld\n",
-                             hp[0], hp[1], hp[2], hp[3], hp[8], hp[9], hp[10]);
-                if (even) { std::swap(xc, xn); ld_x = ld_out; }
-                continue;
-            }
-            static const int t3dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
-            tp.debug = t3dbg;
             HIP_TRY(launch_conv3x3_tile(tp, C, s));
             if (even) {
                 std::swap(xc, xn);

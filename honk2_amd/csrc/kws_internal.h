@@ -139,10 +139,6 @@ struct TileConvParams {
     int Hs, Ws;            // ceil(H / d_in), ceil(W / d_in)
     int total;             // B * d_in^2 * Hs * Ws cells of the input layout
     int terms;
-    int n_cu;              // compute units of the device: the kernel is persistent, one workgroup per CU
-    long long* prof;       // KWS_T3_PROF: 16 device counters of in-kernel phase clocks (workgroup 0), or nullptr
-    int debug;             // KWS_T3_DEBUG, timing experiments only (results are wrong): 1 skip the k-loop, 2 skip the
-                           // staging loads, 4 skip the epilogue
 };
 bool conv3x3_tile_supported(int C, int Cout, int Ws);
 hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
