@@ -17,7 +17,7 @@ DTYPES = {"f32": KWS_DTYPE_F32, "fp32": KWS_DTYPE_F32, "float32": KWS_DTYPE_F32,
 # every symbol include/kws.h declares (tests check the library exports exactly these)
 EXPORTS = (
     "kws_create", "kws_destroy", "kws_load_weights", "kws_workspace_bytes", "kws_set_workspace", "kws_num_frames",
-    "kws_mfcc", "kws_mfcc_pcm16", "kws_forward", "kws_forward_wav", "kws_forward_pcm16", "kws_eval_batch", "kws_plan_name", "kws_profile_enable",
+    "kws_mfcc", "kws_mfcc_pcm16", "kws_forward", "kws_forward_wav", "kws_forward_pcm16", "kws_mfcc_windows", "kws_forward_windows", "kws_eval_batch", "kws_plan_name", "kws_profile_enable",
     "kws_profile_read", "kws_last_error", "kws_abi_version",
 )
 
@@ -80,6 +80,10 @@ def load():
     lib.kws_forward.restype = ci
     lib.kws_forward_wav.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.kws_forward_wav.restype = ci
+    lib.kws_mfcc_windows.argtypes = [vp, vp, sz, ci, ci, ci, vp, vp]
+    lib.kws_mfcc_windows.restype = ci
+    lib.kws_forward_windows.argtypes = [vp, vp, sz, ci, ci, ci, vp, vp]
+    lib.kws_forward_windows.restype = ci
     lib.kws_eval_batch.argtypes = [vp, vp, vp, ci, vp, vp, vp]
     lib.kws_eval_batch.restype = ci
     lib.kws_plan_name.argtypes = [vp]
@@ -253,6 +257,44 @@ class Engine:
         else:
             check(self.lib.kws_forward_wav(self.handle, C.c_void_p(wav.data_ptr()), b, n,
                                            C.c_void_p(out.data_ptr()), self._stream()), "kws_forward_wav")
+        return out
+
+    # ---- streaming: overlapping windows of one long waveform, read in place (reference dataset/dataset_utils.py:20-98)
+    def _stream_args(self, stream, window, shift, first, count):
+        import torch
+        stream = self._check_in(stream, 1, "stream")
+        if stream.dtype != torch.float32:
+            raise ValueError("honk2_amd: the stream must be float32")
+        n = stream.numel()
+        total = 0 if n < window else (n - window) // shift + 1
+        if count is None:
+            count = max(total - first, 0)
+        if first < 0 or count < 0 or first + count > total:
+            raise ValueError(f"honk2_amd: windows [{first}, {first + count}) outside the stream's {total} windows")
+        if (first * shift) % 4:
+            raise ValueError("honk2_amd: first * shift must be a multiple of 4 samples (16-byte aligned window start)")
+        return stream, n - first * shift, first * shift * 4, count
+
+    def mfcc_windows(self, stream, window, shift, first=0, count=None):
+        import torch
+        stream, n_left, byte_off, count = self._stream_args(stream, window, shift, first, count)
+        out = torch.empty((count, self.num_frames(window), self.desc.n_mels), dtype=torch.float32, device=stream.device)
+        if count:
+            check(self.lib.kws_mfcc_windows(self.handle, C.c_void_p(stream.data_ptr() + byte_off), n_left, window, shift,
+                                            count, C.c_void_p(out.data_ptr()), self._stream()), "kws_mfcc_windows")
+        return out
+
+    def forward_windows(self, stream, window, shift, first=0, count=None, out=None):
+        import torch
+        stream, n_left, byte_off, count = self._stream_args(stream, window, shift, first, count)
+        if count:
+            self._ensure_ws(count, self.num_frames(window))
+        if out is None:
+            out = torch.empty((count, self.desc.n_labels), dtype=torch.float32, device=stream.device)
+        if count:
+            check(self.lib.kws_forward_windows(self.handle, C.c_void_p(stream.data_ptr() + byte_off), n_left, window,
+                                               shift, count, C.c_void_p(out.data_ptr()), self._stream()),
+                  "kws_forward_windows")
         return out
 
     def eval_batch(self, logits, target, stats, loss_sum):

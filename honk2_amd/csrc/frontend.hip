@@ -54,9 +54,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(FrontendParams p) {
     {
         // input is either fp32 waveforms, or 16-bit PCM (x / 32768, the on-disk format the reference decodes with
         // librosa.load) with an optional additive noise clip: x += noise * noise_pct (dataset/gsc_dataset.py:163-174)
-        const float* src = p.wav ? p.wav + (size_t)clip * n : nullptr;
-        const short* pcm = p.pcm ? p.pcm + (size_t)clip * n : nullptr;
-        const float* nz = p.noise ? p.noise + (size_t)clip * n : nullptr;
+        // clip_stride == n_samples for a packed batch; smaller for overlapping windows of one long stream read in place
+        const float* src = p.wav ? p.wav + (size_t)clip * p.clip_stride : nullptr;
+        const short* pcm = p.pcm ? p.pcm + (size_t)clip * p.clip_stride : nullptr;
+        const float* nz = p.noise ? p.noise + (size_t)clip * p.clip_stride : nullptr;
         auto sample = [&](int sx) -> float {
 #pragma clang fp contract(off)   // two roundings, like numpy's `data += noise * noise_pct` in float32 (no FMA)
             float v = pcm ? (float)pcm[sx] * (1.0f / 32768.0f) : src[sx];
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(FrontendParams p) {
         };
         constexpr int len4 = (160 * (FE_FRAMES - 1) + FE_NFFT) / 4;     // 4560 groups of 4 samples
         constexpr int iters = (len4 + 255) / 256;                       // 18: all loads are issued before any store
-        const bool vec_ok = (n & 3) == 0 && !pcm && !nz;                // fp32 clip rows 16-byte aligned
+        const bool vec_ok = (p.clip_stride & 3) == 0 && !pcm && !nz;    // fp32 clip rows 16-byte aligned
         f32x4 val[iters];
 #pragma unroll
         for (int it = 0; it < iters; ++it) {

@@ -836,7 +836,7 @@ int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes) {
 }
 
 static int mfcc_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, const float* d_noise, float noise_pct,
-                    int B, int n_samples, float* d_feat, void* stream) {
+                    int B, int n_samples, float* d_feat, void* stream, long long clip_stride = -1) {
     if (!h || (!d_wav && !d_pcm) || !d_feat || B < 0) return fail(KWS_EINVAL, "bad argument");
     if (n_samples <= FE_NFFT / 2) return fail(KWS_EINVAL, "clip shorter than the reflect padding (n_fft/2 + 1 samples needed)");
     if (h->d.n_mels != h->d.freq && h->plan != PLAN_FRONTEND_ONLY) return fail(KWS_EINVAL, "n_mels != model frequency bins");
@@ -846,7 +846,7 @@ static int mfcc_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, con
     if ((rc = prof_mark(h, h->ev_front, s))) return rc;
     FrontendParams p{d_wav, reinterpret_cast<const short*>(d_pcm), d_noise, noise_pct, d_feat, h->dft.as<f32x4>(),
                      h->hann.as<float>(), h->melw.as<float>(), h->mel_lo.as<int>(), h->mel_hi.as<int>(), B, n_samples, T,
-                     h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, h->mel_maxw};
+                     h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, h->mel_maxw, clip_stride < 0 ? n_samples : clip_stride};
     HIP_TRY(launch_frontend(p, s));
     return prof_mark(h, h->ev_front, s);
 }
@@ -874,7 +874,7 @@ int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits,
 }
 
 static int forward_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, const float* d_noise, float noise_pct,
-                       int B, int n_samples, float* d_logits, void* stream) {
+                       int B, int n_samples, float* d_logits, void* stream, long long clip_stride = -1) {
     if (!h || (!d_wav && !d_pcm) || !d_logits || B < 0) return fail(KWS_EINVAL, "bad argument");
     int rc = finalize(h);
     if (rc) return rc;
@@ -882,7 +882,7 @@ static int forward_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, 
     const size_t fb = feat_bytes(h, B, T), ab = act_bytes(h, B, T);
     if ((rc = check_ws(h, fb + ab))) return rc;
     float* feat = static_cast<float*>(h->ws);
-    if ((rc = mfcc_any(h, d_wav, d_pcm, d_noise, noise_pct, B, n_samples, feat, stream))) return rc;
+    if ((rc = mfcc_any(h, d_wav, d_pcm, d_noise, noise_pct, B, n_samples, feat, stream, clip_stride))) return rc;
     char* ws_act = ab ? static_cast<char*>(h->ws) + fb : nullptr;
     return run_model(h, feat, B, T, d_logits, ws_act, static_cast<hipStream_t>(stream));
 }
@@ -894,6 +894,27 @@ int kws_forward_wav(kws_handle* h, const float* d_wav, int B, int n_samples, flo
 int kws_forward_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise, float noise_pct, int B, int n_samples,
                       float* d_logits, void* stream) {
     return forward_any(h, nullptr, d_pcm, d_noise, noise_pct, B, n_samples, d_logits, stream);
+}
+
+static int check_windows(size_t n_stream, int window, int shift, int n_windows) {
+    if (window < 1 || shift < 1 || n_windows < 0) return fail(KWS_EINVAL, "bad window description");
+    if (n_windows > 0 && (size_t)(n_windows - 1) * (size_t)shift + (size_t)window > n_stream)
+        return fail(KWS_EINVAL, "windows run past the end of the stream");
+    return KWS_OK;
+}
+
+int kws_mfcc_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
+                     float* d_feat, void* stream) {
+    int rc = check_windows(n_stream, window, shift, n_windows);
+    if (rc) return rc;
+    return mfcc_any(h, d_stream, nullptr, nullptr, 0.f, n_windows, window, d_feat, stream, shift);
+}
+
+int kws_forward_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
+                        float* d_logits, void* stream) {
+    int rc = check_windows(n_stream, window, shift, n_windows);
+    if (rc) return rc;
+    return forward_any(h, d_stream, nullptr, nullptr, 0.f, n_windows, window, d_logits, stream, shift);
 }
 
 int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target, int B, int64_t* d_stats,

@@ -37,6 +37,7 @@ struct FrontendParams {
     const int* mel_hi;
     int B, n_samples, T, n_mels, chunks;
     int mel_maxw;         // widest mel filter in bins (fast path keeps <= 16 weights in registers)
+    long long clip_stride;   // samples between the starts of consecutive clips (n_samples for a packed batch)
 };
 size_t frontend_lds_bytes(int T);
 hipError_t launch_frontend(const FrontendParams& p, hipStream_t s);

@@ -11,6 +11,11 @@ batch with ``torch.cat`` one clip at a time.  Here ``collate_fn`` only stacks th
 tensor (safe inside DataLoader worker processes, no GPU use there); iteration in the main process moves that
 tensor to the device and makes ONE ``kws_mfcc`` call.  Each iteration yields ``(features (B, T, 40) on the GPU,
 targets LongTensor)`` -- the same pair ``evaluate`` (``run/test.py:22-23``) consumes.
+
+Streaming datasets (reference ``dataset/dataset_utils.py:20-98``: item i is a 1000 ms window shifted by 10 ms) take a
+shortcut when they are iterated in order: the dataset exposes its whole stream (``stream_view()``), which goes to the GPU
+ONCE, and every batch is one ``kws_mfcc_windows`` call over overlapping windows read in place, instead of ``batch_size``
+host-side window copies that are 99 % redundant.
 """
 import numpy as np
 import torch
@@ -28,6 +33,7 @@ class AudioDataLoader(DataLoader):
                              "(PCEN is dead code in the reference and out of scope)")
         self.audio_processor = AudioProcessor()
         self.raw_waveforms = bool(data_loader_config.get("raw_waveforms", False))
+        self._shuffled = bool(data_loader_config.get("shuffle", False))
         super().__init__(
             dataset=dataset,
             batch_size=data_loader_config["batch_size"],
@@ -48,6 +54,16 @@ class AudioDataLoader(DataLoader):
         if not torch.cuda.is_available():
             raise RuntimeError("honk2_amd: AudioDataLoader needs a ROCm device for the MFCC front end (no CPU path)")
         device = torch.device("cuda", torch.cuda.current_device())
+        if hasattr(self.dataset, "stream_view") and not self.raw_waveforms and not self._shuffled:
+            stream, window, shift, targets = self.dataset.stream_view()
+            stream = torch.from_numpy(np.ascontiguousarray(stream)).to(device)
+            targets = torch.from_numpy(np.ascontiguousarray(targets))
+            n = len(targets)
+            if n and (shift % 4 == 0):
+                for b0 in range(0, n, self.batch_size):
+                    nb = min(self.batch_size, n - b0)
+                    yield self.audio_processor.compute_mfccs_windows(stream, window, shift, b0, nb), targets[b0:b0 + nb]
+                return
         for wav, target in super().__iter__():
             wav = wav.to(device, non_blocking=True)
             yield (wav if self.raw_waveforms else self.audio_processor.compute_mfccs_batch(wav)), target

@@ -1,2 +1,2 @@
-from .dataset_utils import DatasetType
-from .synthetic_dataset import SyntheticKWSDataset
+from .dataset_utils import DatasetType, StreamingDataset, shuffle_in_groups
+from .synthetic_dataset import SyntheticKWSDataset, SyntheticStreamingDataset

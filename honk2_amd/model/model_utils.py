@@ -101,5 +101,12 @@ class BaseModel(ABC, nn.Module):
         with torch.no_grad():
             return self.engine().forward_wav(wav, out, noise, noise_pct)
 
+    def forward_windows(self, stream, window, shift, first=0, count=None, out=None):
+        """Streaming evaluation: 1-D float32 stream on the GPU -> logits of the windows ``stream[i*shift : i*shift +
+        window]`` (reference ``dataset/dataset_utils.py:20-98``), read in place by ``kws_forward_windows``."""
+        self._require_eval()
+        with torch.no_grad():
+            return self.engine().forward_windows(stream, window, shift, first, count, out)
+
     def plan_name(self):
         return self.engine().plan_name()

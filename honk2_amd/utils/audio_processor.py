@@ -41,6 +41,11 @@ class AudioProcessor(object):
         """(B, n) float32 or int16-PCM tensor on the GPU -> (B, T, n_mels) float32 tensor on the GPU."""
         return self._get_engine().mfcc(wav, noise, noise_pct)
 
+    def compute_mfccs_windows(self, stream, window, shift, first=0, count=None):
+        """1-D float32 stream on the GPU -> features (count, T, n_mels) of the windows ``stream[i*shift : i*shift + window]``,
+        ``i = first .. first + count - 1`` (the items of the reference's ``StreamingDataset``), read in place."""
+        return self._get_engine().mfcc_windows(stream, window, shift, first, count)
+
     def compute_mfccs(self, data):
         import torch
         eng = self._get_engine()

@@ -13,6 +13,7 @@
  *                        + AudioProcessor.__init__            utils/audio_processor.py:8-16
  *   kws_load_weights  <- model.load_state_dict               utils/workspace.py:58-61
  *   kws_*_pcm16       <- librosa.load int16->float + `data += noise * noise_pct`   dataset/gsc_dataset.py:163-174
+ *   kws_*_windows     <- StreamingDataset.__getitem__ (sliding windows of one long stream)   dataset/dataset_utils.py:20-98
  *   kws_eval_batch    <- loss_fn + metric.accumulate          run/test.py:28-33, loss_function.py:6-9,
  *                                                             metric/acc.py:14-24, metric/per_class_acc.py:14-45
  *
@@ -123,6 +124,15 @@ int kws_forward_wav(kws_handle* h, const float* d_wav, int B, int n_samples, flo
 /* pcm16 (B, n_samples) [+ noise] -> logits. */
 int kws_forward_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise, float noise_pct, int B, int n_samples,
                       float* d_logits, void* stream);
+
+/* Streaming evaluation: window i of a long stream is d_stream[i*shift : i*shift + window] (window_size_ms / shift_size_ms of
+ * the reference's streaming datasets, in samples); every window takes the usual path (its own reflect padding included,
+ * exactly as if it had been copied out), but the windows are read in place -- no (n_windows, window) batch is built.
+ * (n_windows - 1) * shift + window must not exceed n_stream. */
+int kws_mfcc_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
+                     float* d_feat, void* stream);
+int kws_forward_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
+                        float* d_logits, void* stream);
 
 /* Evaluation tail, fused: adds to d_stats (int64[2 + 2*n_labels] = correct, total, per-class correct[n],
  * per-class total[n]) and to d_loss_sum (double[1]: sum over clips of the cross-entropy, natural log). */

@@ -331,6 +331,48 @@ def test_entry_point_with_reference_checkpoint_and_odd_clip_length(torch_cuda, t
     assert np.abs(y - want).max() < LOGIT_TOL and (y.argmax(1) == want.argmax(1)).all()
 
 
+def test_streaming_windows_read_in_place(torch_cuda):
+    """kws_mfcc_windows / kws_forward_windows (reference dataset/dataset_utils.py:20-98: item i is stream[i*shift : i*shift +
+    window]) must give exactly what copying every window out and taking the batched path gives -- each window keeps its
+    own reflect padding -- and the loader's streaming shortcut must yield the same batches as item-by-item collation."""
+    torch = torch_cuda
+    import random
+    from honk2_amd.data_loader import AudioDataLoader
+    from honk2_amd.dataset import SyntheticStreamingDataset
+    from honk2_amd.utils import AudioProcessor
+    from oracle import frontend, models, weights
+    cfg = dict(sample_rate=16000, target_class=["yes", "no", "up"], unknown_class=True, silence_class=True, type="dev",
+               window_size_ms=1000, shift_size_ms=10, num_files=4, seed=3)
+    random.seed(7)
+    ds = SyntheticStreamingDataset(cfg)
+    stream, window, shift, targets = ds.stream_view()
+    n = len(ds)
+    assert n == 300 and len(targets) == n
+    gs = torch.from_numpy(stream).cuda()
+    stacked = torch.from_numpy(np.stack([stream[i * shift:i * shift + window] for i in range(n)])).cuda()
+    ap = AudioProcessor()
+    f_win = ap.compute_mfccs_windows(gs, window, shift)
+    f_ref = ap.compute_mfccs_batch(stacked)
+    assert f_win.shape == (n, 101, 40) and torch.equal(f_win, f_ref)
+    part = ap.compute_mfccs_windows(gs, window, shift, first=100, count=37)
+    assert torch.equal(part, f_ref[100:137])
+    want = frontend.compute_mfccs_batch(stream[None, 5 * shift:5 * shift + window], "f64")[0]      # oracle on one window
+    assert np.abs(f_win[5].cpu().numpy() - want).max() < 2e-2
+    mcfg = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 5}
+    sd = weights.make_state_dict("ResNet", mcfg, seed=2)
+    model = _build(torch, "ResNet", mcfg, sd)
+    assert torch.equal(model.forward_windows(gs, window, shift), model.forward_wav(stacked))
+    with pytest.raises(ValueError):
+        model.forward_windows(gs, window, shift, first=n - 3, count=10)
+    # loader: streaming shortcut == generic path (forced by asking for raw waveforms and running the front end by hand)
+    fast = list(AudioDataLoader({"audio_preprocessing": "MFCCs", "batch_size": 128}, ds))
+    slow = list(AudioDataLoader({"audio_preprocessing": "MFCCs", "batch_size": 128, "raw_waveforms": True}, ds))
+    assert len(fast) == len(slow) == 3
+    for (ff, ft), (sw, st) in zip(fast, slow):
+        assert torch.equal(ft, st) and torch.equal(ff, ap.compute_mfccs_batch(sw))
+    assert torch.equal(torch.cat([t for _, t in fast]), torch.from_numpy(targets))
+
+
 def test_data_loader_and_entry_point(torch_cuda, tmp_path):
     torch = torch_cuda
     from honk2_amd.run.test import main

@@ -169,3 +169,33 @@ def test_reference_written_checkpoint_loads(tmp_path):
     assert isinstance(extra["metrics"]["PerClassAcc"], PerClassAcc)
     model = find_cls(f"model.{name}")(dict(cfg))
     model.load_state_dict(sd, strict=True)
+
+
+# ------------------------------------------------------------------ streaming dataset mirror
+@pytest.mark.parametrize("tag,case", [("w1000_s10", dict(window_size_ms=1000, shift_size_ms=10, num_files=9, seed=77)),
+                                      ("w400_s30", dict(window_size_ms=400, shift_size_ms=30, num_files=14, seed=5))])
+def test_streaming_dataset_matches_the_reference_class(tag, case):
+    """tests/golden/streaming_dataset.npz was produced by the reference's own StreamingDataset (dataset/dataset_utils.py:
+    20-98) over the same synthetic utterances (oracle/gen_golden_streaming.py): same windows, same majority-label targets,
+    same length -- read here out of order, which the reference cannot do."""
+    import random
+    from honk2_amd.dataset import SyntheticStreamingDataset
+    z = np.load(os.path.join(GOLDEN, "streaming_dataset.npz"))
+    cfg = dict(sample_rate=16000, target_class=["yes", "no", "up"], unknown_class=True, silence_class=True, type="dev", **case)
+    random.seed(1234)
+    ds = SyntheticStreamingDataset(cfg)
+    n = int(z[f"{tag}_len"])
+    assert len(ds) == n
+    order = np.random.default_rng(0).permutation(n)[:200]
+    for i in order:
+        w, t = ds[int(i)]
+        assert t == int(z[f"{tag}_targets"][i])
+        assert len(w) == ds.window_size and w.dtype == np.float32
+        assert abs(float(np.asarray(w, np.float64).sum()) - float(z[f"{tag}_sums"][i])) < 1e-9
+        assert (float(w[0]), float(w[-1])) == tuple(z[f"{tag}_ends"][i])
+    stream, window, shift, targets = ds.stream_view()
+    assert (window, shift) == (ds.window_size, ds.shift_size)
+    assert np.array_equal(targets, z[f"{tag}_targets"])
+    assert len(stream) == (n - 1) * shift + window
+    w5, _ = ds[5]
+    assert np.array_equal(stream[5 * shift:5 * shift + window], w5)
