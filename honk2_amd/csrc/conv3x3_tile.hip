@@ -91,8 +91,10 @@ __device__ __forceinline__ int layout_cell(int b, int y, int x, int ld, int H, i
         TMF(A3[1], B3[1], C_); \
         TMF(A3[0], B3[2], C_); \
     }                          \
-    TMF(A3[1], B3[0], C_);     \
-    TMF(A3[0], B3[1], C_);     \
+    if (TERMS >= 3) {          \
+        TMF(A3[1], B3[0], C_); \
+        TMF(A3[0], B3[1], C_); \
+    }                          \
     TMF(A3[0], B3[0], C_);
 }  // namespace
 
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
     constexpr int CELL = NB * 48, PART = NB * 16;   // LDS cell: 3 parts x NB*8 channels x 2 B
     constexpr int GCELL = NB * 32;                  // global cell: NB*8 channels x 4 B
     constexpr int STEPS = (9 * NB + 3) / 4;
-    constexpr int NP = TERMS == 6 ? 3 : 2;
+    constexpr int NP = TERMS == 6 ? 3 : (TERMS == 3 ? 2 : 1);   // parts that take part in the products
     constexpr int NQ = NB * 2;         // 4-channel quads per cell
     constexpr int NGRP = 256 / NQ;     // cells copied per pass (21 / 42)
     constexpr int UNR = NB == 6 ? 14 : 7;  // passes in flight together: a whole tile for W <= 40
@@ -308,15 +310,20 @@ static hipError_t launch_t3(const TileConvParams& p, hipStream_t s) {
     const size_t lds = conv3x3_tile_lds_bytes(NB * 8, p.Ws);
     auto k6 = conv3x3_tile_kernel<NB, MT, 6>;
     auto k3 = conv3x3_tile_kernel<NB, MT, 3>;
+    auto k1 = conv3x3_tile_kernel<NB, MT, 1>;
     static bool attr_done = false;   // per instantiation: allow > 64 KB of dynamic LDS
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (p.terms == 3)
+    if (p.terms == 1)
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, s, p);
+    else if (p.terms == 3)
         hipLaunchKernelGGL(k3, dim3(grid), dim3(256), lds, s, p);
     else
         hipLaunchKernelGGL(k6, dim3(grid), dim3(256), lds, s, p);

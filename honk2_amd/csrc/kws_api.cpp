@@ -406,6 +406,8 @@ ResnetShape resnet_shape(const kws_handle* h, int T) {
 }
 
 int pad8(int c) { return (c + 7) / 8 * 8; }
+// bf16 product terms per fp32 product: 6 = fp32-accurate, 3 = KWS_DTYPE_BF16X3, 1 = plain bf16 operands
+int dtype_terms(int dtype) { return dtype == KWS_DTYPE_BF16X3 ? 3 : dtype == KWS_DTYPE_BF16 ? 1 : 6; }
 int ilog2(int d) { int l = 0; while ((1 << l) < d) ++l; return l; }
 
 // LDS-tiled 3x3 kernel usable for every conv_i of this ResNet?
@@ -505,7 +507,7 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
     float* X = (float*)ws; ws += align256(cl * cb * 4);
     float* X2 = (float*)ws; ws += align256(cl * cb * 4);
     float* Y = (float*)ws;
-    const int terms = d.dtype == KWS_DTYPE_BF16X3 ? 3 : 6;
+    const int terms = dtype_terms(d.dtype);
     int rc;
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
@@ -560,7 +562,7 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
     float* X = (float*)ws; ws += align256(small * cb * 4);
     float* Y = (float*)ws;
     const int C = sh.C;
-    const int terms = d.dtype == KWS_DTYPE_BF16X3 ? 3 : 6;
+    const int terms = dtype_terms(d.dtype);
     int rc;
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
@@ -617,7 +619,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
     float* P = (float*)ws;
     float* Q = (float*)(ws + align256(h->cnn_max_elems * cb * 4));
     float* part = (float*)(ws + 2 * align256(h->cnn_max_elems * cb * 4));
-    const int terms = d.dtype == KWS_DTYPE_BF16X3 ? 3 : 6;
+    const int terms = dtype_terms(d.dtype);
     const size_t part_bytes = cnn_partial_bytes(h, cb);
     auto other = [&](const float* c) -> float* { return c == P ? Q : P; };
     for (int b0 = 0; b0 < B; b0 += cb) {
@@ -665,7 +667,7 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 h->last_plan = "res8_fused";
                 Res8xParams p{feat, logits, h->r8_w0a.as<float>(), h->r8x_apk.p, h->r8_bn.as<float>(),
                               h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq, h->d.n_labels, dbg,
-                              h->d.dtype == KWS_DTYPE_BF16X3 ? 3 : 6};
+                              dtype_terms(h->d.dtype)};
                 HIP_TRY(launch_res8x(p, std::min(B, 256), s));
             }
         } else {
@@ -707,8 +709,8 @@ const char* kws_last_error(void) { return g_err.c_str(); }
 int kws_create(const kws_model_desc* desc, kws_handle** out) {
     if (!desc || !out) return fail(KWS_EINVAL, "null argument");
     if (desc->struct_size != (int)sizeof(kws_model_desc)) return fail(KWS_EINVAL, "kws_model_desc size mismatch (ABI)");
-    if (desc->dtype != KWS_DTYPE_F32 && desc->dtype != KWS_DTYPE_BF16X3)
-        return fail(KWS_EUNSUPPORTED, "dtype must be KWS_DTYPE_F32 or KWS_DTYPE_BF16X3");
+    if (desc->dtype != KWS_DTYPE_F32 && desc->dtype != KWS_DTYPE_BF16X3 && desc->dtype != KWS_DTYPE_BF16)
+        return fail(KWS_EUNSUPPORTED, "dtype must be KWS_DTYPE_F32, KWS_DTYPE_BF16X3 or KWS_DTYPE_BF16");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return fail(KWS_EHIP, "no HIP device available: the HIP path is mandatory, there is no CPU fallback");

@@ -63,8 +63,10 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[3]) {
         XMF(A3[1], B3[1], C_); \
         XMF(A3[0], B3[2], C_); \
     }                          \
-    XMF(A3[1], B3[0], C_);     \
-    XMF(A3[0], B3[1], C_);     \
+    if (TERMS >= 3) {          \
+        XMF(A3[1], B3[0], C_); \
+        XMF(A3[0], B3[1], C_); \
+    }                          \
     XMF(A3[0], B3[0], C_);
 }  // namespace
 
@@ -217,7 +219,12 @@ template <int MT>
 static hipError_t launch_x_mt(const ConvGeom& g, const ConvArgs& a, hipStream_t s) {
     const long long ntot = (long long)g.B * g.Ho * g.Wo;
     dim3 grid((unsigned)((ntot + 255) / 256), (unsigned)((g.mtiles + MT - 1) / MT), (unsigned)(g.ksplit > 1 ? g.ksplit : 1));
-    if (g.x_terms == 3) {
+    if (g.x_terms == 1) {
+        if (g.kx_inner)
+            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, true, 1>), grid, dim3(256), 0, s, g, a);
+        else
+            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, false, 1>), grid, dim3(256), 0, s, g, a);
+    } else if (g.x_terms == 3) {
         if (g.kx_inner)
             hipLaunchKernelGGL((conv_bf16x6_kernel<MT, true, 3>), grid, dim3(256), 0, s, g, a);
         else

