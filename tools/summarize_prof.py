@@ -13,21 +13,22 @@ def main(src, tag, dst="profiles/r01"):
     os.makedirs(dst, exist_ok=True)
     summary = {}
     for path in glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True):
-        rows = [r for r in csv.DictReader(open(path)) if r["Name"].startswith("kws::") or "nccl" in r["Name"].lower()]
+        rows = [r for r in csv.DictReader(open(path)) if "kws::" in r["Name"] or "nccl" in r["Name"].lower()]
         with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
             w.writeheader()
             w.writerows(rows)
         for r in rows:
-            summary.setdefault(r["Name"].split("(")[0], {})["avg_ms"] = float(r["AverageNs"]) / 1e6
-            summary[r["Name"].split("(")[0]]["calls"] = int(r["Calls"])
+            name = r["Name"].split("(")[0].replace("void ", "")
+            summary.setdefault(name, {})["avg_ms"] = float(r["AverageNs"]) / 1e6
+            summary[name]["calls"] = int(r["Calls"])
     for path in glob.glob(os.path.join(src, "**", "*_counter_collection.csv"), recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
         for r in csv.DictReader(open(path)):
-            if not r["Kernel_Name"].startswith("kws::"):
+            if "kws::" not in r["Kernel_Name"]:
                 continue
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = {"vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
                        "lds": int(r["LDS_Block_Size"]), "scratch": int(r["Scratch_Size"]), "grid": int(r["Grid_Size"])}
