@@ -630,8 +630,19 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             g.B = nb;
             float* conv_out_buf = other(cur);
             ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), nullptr, h->cconv[i].bias.as<float>(), nullptr, nullptr};
+            const int members = d.pool_kh[i] * d.pool_kw[i];
+            // MaxPool windows of up to four outputs are reduced in the conv's accumulators (bf16x6 kernel); 1 x 1 pools
+            // (every pool_1 of the shipped configs) are the identity
+            if (h->cconv[i].use_x && members >= 2 && members <= 4) {
+                g.pool_h = d.pool_kh[i];
+                g.pool_w = d.pool_kw[i];
+            }
             int rcc = launch_layer(h->cconv[i], g, a, s, terms);
             if (rcc) return rcc;
+            if (g.pool_h || members == 1) {
+                cur = conv_out_buf;
+                continue;
+            }
             float* pooled = other(conv_out_buf);
             HIP_TRY(launch_pool(conv_out_buf, pooled, nb * g.Cout, g.Ho, g.Wo, d.pool_kh[i], d.pool_kw[i], 1, s));
             cur = pooled;

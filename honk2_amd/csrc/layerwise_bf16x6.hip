@@ -77,22 +77,32 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
     const int pcol = lane & 15;
-    const int npc = gm.Ho * gm.Wo;
+    // Fused max-pool mode (gm.pool_h * gm.pool_w in 2..4, stride = window, floor): a wave owns 16 POOLED positions and its
+    // four position tiles are the members of their windows, so the maximum is taken over accumulators of one lane and
+    // the un-pooled map never exists.  Otherwise a wave owns 64 consecutive output positions.
+    const int nmem = gm.pool_h * gm.pool_w > 1 ? gm.pool_h * gm.pool_w : 0;   // 0: no pooling
+    const int Hq = nmem ? gm.Ho / gm.pool_h : gm.Ho, Wq = nmem ? gm.Wo / gm.pool_w : gm.Wo;
+    const int npc = Hq * Wq;
     const long long ntot = (long long)gm.B * npc;
-    const long long n0 = ((long long)blockIdx.x * 4 + w) * 64;
+    const long long n0 = ((long long)blockIdx.x * 4 + w) * (nmem ? 16 : 64);
     const int hw = gm.H * gm.W;
 
     bool valid[4];
     int iy0[4], ix0[4], inb[4], pos[4], bidx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const long long n = n0 + 16 * j + pcol;
-        valid[j] = n < ntot;
-        const long long nn = valid[j] ? n : ntot - 1;
+        const long long n = nmem ? n0 + pcol : n0 + 16 * j + pcol;
+        valid[j] = n < ntot && (!nmem || j < nmem);
+        const long long nn = n < ntot ? n : ntot - 1;
         const int b = (int)(nn / npc);
         const int ps = (int)(nn - (long long)b * npc);
-        const int oy = ps / gm.Wo;
-        const int ox = ps - oy * gm.Wo;
+        int oy = ps / Wq;
+        int ox = ps - oy * Wq;
+        if (nmem) {
+            const int dy = j / gm.pool_w;
+            oy = oy * gm.pool_h + dy;
+            ox = ox * gm.pool_w + (j - dy * gm.pool_w);
+        }
         bidx[j] = b;
         pos[j] = ps;
         iy0[j] = oy * gm.sh - gm.ph;
@@ -159,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
             _Pragma("unroll") for (int pt = 0; pt < 3; ++pt)                                          \
                 wa_[m][pt] = bload4(rwt, lane * 16 + (m * 3 + pt) * 1024, (S) * MT * 3 * 1024);       \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            if (nmem && j >= nmem) continue;   /* 1 x 3 windows: the fourth tile has no member (uniform branch) */ \
             u32x4 bs_[3];                                                                             \
             split8(RAW[j], bs_);                                                                      \
             _Pragma("unroll") for (int m = 0; m < MT; ++m) { XMF6(wa_[m], bs_, acc[m][j]) }           \
@@ -198,6 +209,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
             const int co = ((int)blockIdx.y * MT + m) * 16 + 4 * g + r;
             if (co >= gm.Cout) continue;
             const float bias = a.bias ? a.bias[co] : 0.f;
+            if (nmem) {   // max over the window, then bias + ReLU (both monotone, so the order does not matter)
+                if (!valid[0]) continue;
+                float v = acc[m][0][r];
+#pragma unroll
+                for (int j = 1; j < 4; ++j)
+                    if (j < nmem) v = fmaxf(v, acc[m][j][r]);
+                v += bias;
+                if (gm.relu) v = fmaxf(v, 0.f);
+                a.out[((size_t)bidx[0] * gm.Cout + co) * npc + pos[0]] = v;
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!valid[j]) continue;
@@ -217,8 +239,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
 
 template <int MT>
 static hipError_t launch_x_mt(const ConvGeom& g, const ConvArgs& a, hipStream_t s) {
-    const long long ntot = (long long)g.B * g.Ho * g.Wo;
-    dim3 grid((unsigned)((ntot + 255) / 256), (unsigned)((g.mtiles + MT - 1) / MT), (unsigned)(g.ksplit > 1 ? g.ksplit : 1));
+    const bool pooled = g.pool_h * g.pool_w > 1;
+    const long long ntot = pooled ? (long long)g.B * (g.Ho / g.pool_h) * (g.Wo / g.pool_w) : (long long)g.B * g.Ho * g.Wo;
+    const int per_wg = pooled ? 64 : 256;
+    dim3 grid((unsigned)((ntot + per_wg - 1) / per_wg), (unsigned)((g.mtiles + MT - 1) / MT), (unsigned)(g.ksplit > 1 ? g.ksplit : 1));
     if (g.x_terms == 1) {
         if (g.kx_inner)
             hipLaunchKernelGGL((conv_bf16x6_kernel<MT, true, 1>), grid, dim3(256), 0, s, g, a);
@@ -247,6 +271,9 @@ bool conv_bf16x6_supported(const ConvGeom& g) {
 
 hipError_t launch_conv_bf16x6(const ConvGeom& g, const ConvArgs& a, hipStream_t s) {
     if (g.B <= 0) return hipSuccess;
+    if (g.pool_h * g.pool_w > 1 && (g.pool_h * g.pool_w > 4 || g.ksplit > 1 || g.accumulate || a.border ||
+                                    g.Ho < g.pool_h || g.Wo < g.pool_w))
+        return hipErrorInvalidValue;
     switch (g.MT) {
         case 1: return launch_x_mt<1>(g, a, s);
         case 2: return launch_x_mt<2>(g, a, s);
