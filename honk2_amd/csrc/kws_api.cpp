@@ -447,7 +447,8 @@ int chunk_clips(size_t per_clip_elems, int B) {
 // Linears (flat Cin == 1 "convs") over a chunk of clips launch only B/256 workgroups; split K so the chip is filled.
 int plan_ksplit(const ConvGeom& g, int nb, int steps) {
     if (!(g.kx_inner && g.ph == 0 && g.pw == 0)) return 1;
-    const long long wgs = (((long long)nb * g.Ho * g.Wo + 255) / 256) * ((g.mtiles + g.MT - 1) / g.MT);
+    const int mt = g.x_mt > 0 ? g.x_mt : g.MT;
+    const long long wgs = (((long long)nb * g.Ho * g.Wo + 255) / 256) * ((g.mtiles + mt - 1) / mt);
     if (wgs >= 256 || steps < 64) return 1;
     int ks = (int)std::min<long long>((1024 + wgs - 1) / wgs, steps / 16);
     return std::max(1, std::min(ks, 256));

@@ -105,7 +105,8 @@ struct ConvGeom {
     int x_blocks_per_row;  // bf16x6 kernel: blocks of 8 per tap (ceil(Cin/8)) or per kernel row (ceil(kw/8))
     int x_blocks;          // total K blocks of 8
     int x_ksteps;          // ceil(x_blocks / 4): k-steps of v_mfma_f32_16x16x32_bf16
-    int x_terms;           // bf16 kernel: 6 (fp32-accurate) or 3 (KWS_DTYPE_BF16X3)
+    int x_mt;              // bf16 kernel: channel tiles per wave (conv_bf16x6_geometry)
+    int x_terms;           // bf16 kernel: 6 (fp32-accurate), 3 (KWS_DTYPE_BF16X3) or 1 (KWS_DTYPE_BF16)
     int pool_h, pool_w;    // conv_bf16x6_kernel only: fused MaxPool window (stride = window, floor), <= 4 members; 0 / 1 = none
     int ksplit;            // > 1: K range split over blockIdx.z (flat Cin == 1 mode only); partial sums go to ConvArgs::partial
     int ksteps_split;      // k-steps per split

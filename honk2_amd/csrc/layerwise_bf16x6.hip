@@ -274,7 +274,7 @@ hipError_t launch_conv_bf16x6(const ConvGeom& g, const ConvArgs& a, hipStream_t 
     if (g.pool_h * g.pool_w > 1 && (g.pool_h * g.pool_w > 4 || g.ksplit > 1 || g.accumulate || a.border ||
                                     g.Ho < g.pool_h || g.Wo < g.pool_w))
         return hipErrorInvalidValue;
-    switch (g.MT) {
+    switch (g.x_mt) {
         case 1: return launch_x_mt<1>(g, a, s);
         case 2: return launch_x_mt<2>(g, a, s);
         case 3: return launch_x_mt<3>(g, a, s);
@@ -308,17 +308,30 @@ void conv_bf16x6_geometry(ConvGeom& g) {
         g.x_blocks = g.kh * g.kw * g.x_blocks_per_row;
     }
     g.x_ksteps = (g.x_blocks + 3) / 4;
+    // Channel tiles per wave.  Per k-step a wave pays the gather + split of its four B fragments once (~800 cycles of VALU
+    // issue) and 4 x 6 MFMAs (384 cycles) per channel tile; the grid repeats that for every group of MT tiles, so few
+    // groups matter more than a fully used last group (Cout = 78: MT = 3 over 2 groups beats MT = 1 over 5).
+    int best = 1;
+    long long best_cost = -1;
+    for (int mt = 1; mt <= 4; ++mt) {
+        const long long cost = (long long)((g.mtiles + mt - 1) / mt) * (800 + 384 * mt);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = mt;
+        }
+    }
+    g.x_mt = best;
 }
 
 // weights (Cout, Cin, kh, kw) -> [mgroup][k-step][MT][part][lane][8 bf16]; lane = (block slot g << 4) | row
 void pack_conv_weights_bf16x6(const ConvGeom& g, const float* w, std::vector<unsigned short>& dst) {
-    const int mgroups = (g.mtiles + g.MT - 1) / g.MT;
-    dst.assign((size_t)mgroups * g.x_ksteps * g.MT * 3 * 64 * 8, 0);
+    const int mgroups = (g.mtiles + g.x_mt - 1) / g.x_mt;
+    dst.assign((size_t)mgroups * g.x_ksteps * g.x_mt * 3 * 64 * 8, 0);
     for (int mg = 0; mg < mgroups; ++mg)
         for (int s = 0; s < g.x_ksteps; ++s)
-            for (int m = 0; m < g.MT; ++m)
+            for (int m = 0; m < g.x_mt; ++m)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int co = (mg * g.MT + m) * 16 + (lane & 15);
+                    const int co = (mg * g.x_mt + m) * 16 + (lane & 15);
                     const int bi = 4 * s + (lane >> 4);
                     const int r = bi / g.x_blocks_per_row, cb = bi % g.x_blocks_per_row;
                     for (int e = 0; e < 8; ++e) {
@@ -338,7 +351,7 @@ void pack_conv_weights_bf16x6(const ConvGeom& g, const float* w, std::vector<uns
                         const unsigned short l = bf16_rne_h(r1 - bf16_to_f_h(mm));
                         const unsigned short parts[3] = {h, mm, l};
                         for (int pt = 0; pt < 3; ++pt)
-                            dst[(((((size_t)mg * g.x_ksteps + s) * g.MT + m) * 3 + pt) * 64 + lane) * 8 + e] = parts[pt];
+                            dst[(((((size_t)mg * g.x_ksteps + s) * g.x_mt + m) * 3 + pt) * 64 + lane) * 8 + e] = parts[pt];
                     }
                 }
 }
