@@ -247,6 +247,7 @@ int build_cnn(kws_handle* h) {
         ConvGeom g = make_geom(C, c.out_channels, c.kernel_h, c.kernel_w, c.stride_h, c.stride_w, 0, 0, 1, 1, 1);
         set_spatial(g, 0, H, W);
         if (g.Ho < 1 || g.Wo < 1) return fail(KWS_EINVAL, "conv kernel larger than its input");
+        if (d.pool_kh[i] * d.pool_kw[i] > 4) g.x_mt_cap = 3;   // multi-pass fused pooling exists for <= 3 channel tiles per wave
         h->cconv[i].g = g;
         h->cconv[i].has_bias = true;
         mx = std::max(mx, (size_t)g.Cout * g.Ho * g.Wo);
@@ -632,9 +633,9 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             float* conv_out_buf = other(cur);
             ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), nullptr, h->cconv[i].bias.as<float>(), nullptr, nullptr};
             const int members = d.pool_kh[i] * d.pool_kw[i];
-            // MaxPool windows of up to four outputs are reduced in the conv's accumulators (bf16x6 kernel); 1 x 1 pools
-            // (every pool_1 of the shipped configs) are the identity
-            if (h->cconv[i].use_x && members >= 2 && members <= 4) {
+            // MaxPool windows are reduced in the conv's accumulators (bf16x6 kernel, up to four members per pass over K);
+            // 1 x 1 pools (every pool_1 of the shipped configs) are the identity
+            if (h->cconv[i].use_x && members >= 2 && members <= 16) {
                 g.pool_h = d.pool_kh[i];
                 g.pool_w = d.pool_kw[i];
             }

@@ -106,8 +106,9 @@ struct ConvGeom {
     int x_blocks;          // total K blocks of 8
     int x_ksteps;          // ceil(x_blocks / 4): k-steps of v_mfma_f32_16x16x32_bf16
     int x_mt;              // bf16 kernel: channel tiles per wave (conv_bf16x6_geometry)
+    int x_mt_cap;          // > 0: upper bound for x_mt (3 for convs whose pooling window needs several passes)
     int x_terms;           // bf16 kernel: 6 (fp32-accurate), 3 (KWS_DTYPE_BF16X3) or 1 (KWS_DTYPE_BF16)
-    int pool_h, pool_w;    // conv_bf16x6_kernel only: fused MaxPool window (stride = window, floor), <= 4 members; 0 / 1 = none
+    int pool_h, pool_w;    // conv_bf16x6_kernel only: fused MaxPool window (stride = window, floor), <= 16 members; 0 / 1 = none
     int ksplit;            // > 1: K range split over blockIdx.z (flat Cin == 1 mode only); partial sums go to ConvArgs::partial
     int ksteps_split;      // k-steps per split
 };

@@ -70,17 +70,21 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[3]) {
     XMF(A3[0], B3[0], C_);
 }  // namespace
 
-template <int MT, bool KX, int TERMS>
+// MULTI: pooling windows of more than four members (several passes over K with a running maximum)
+template <int MT, bool KX, int TERMS, bool MULTI>
 __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
     const int pcol = lane & 15;
-    // Fused max-pool mode (gm.pool_h * gm.pool_w in 2..4, stride = window, floor): a wave owns 16 POOLED positions and its
-    // four position tiles are the members of their windows, so the maximum is taken over accumulators of one lane and
-    // the un-pooled map never exists.  Otherwise a wave owns 64 consecutive output positions.
+    // Fused max-pool mode (gm.pool_h * gm.pool_w > 1, stride = window, floor): a wave owns 16 POOLED positions and its
+    // position tiles are members of their windows -- up to four per pass over K, windows of 6 / 9 members in passes of three
+    // -- so the maximum is taken over accumulators of one lane and the un-pooled map never exists.  Otherwise a wave owns
+    // 64 consecutive output positions (one pass).
     const int nmem = gm.pool_h * gm.pool_w > 1 ? gm.pool_h * gm.pool_w : 0;   // 0: no pooling
+    const int per_pass = nmem == 0 ? 4 : (nmem <= 4 ? nmem : (nmem % 3 == 0 ? 3 : 4));
+    const int npass = MULTI ? (nmem + per_pass - 1) / per_pass : 1;
     const int Hq = nmem ? gm.Ho / gm.pool_h : gm.Ho, Wq = nmem ? gm.Wo / gm.pool_w : gm.Wo;
     const int npc = Hq * Wq;
     const long long ntot = (long long)gm.B * npc;
@@ -89,26 +93,32 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
 
     bool valid[4];
     int iy0[4], ix0[4], inb[4], pos[4], bidx[4];
+    int ntile = 4;   // position tiles in use in the current pass (uniform)
+    auto setup_tiles = [&](int pass) {
+        ntile = nmem ? min(per_pass, nmem - pass * per_pass) : 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long long n = nmem ? n0 + pcol : n0 + 16 * j + pcol;
-        valid[j] = n < ntot && (!nmem || j < nmem);
-        const long long nn = n < ntot ? n : ntot - 1;
-        const int b = (int)(nn / npc);
-        const int ps = (int)(nn - (long long)b * npc);
-        int oy = ps / Wq;
-        int ox = ps - oy * Wq;
-        if (nmem) {
-            const int dy = j / gm.pool_w;
-            oy = oy * gm.pool_h + dy;
-            ox = ox * gm.pool_w + (j - dy * gm.pool_w);
+        for (int j = 0; j < 4; ++j) {
+            const long long n = nmem ? n0 + pcol : n0 + 16 * j + pcol;
+            valid[j] = n < ntot && j < ntile;
+            const long long nn = n < ntot ? n : ntot - 1;
+            const int b = (int)(nn / npc);
+            const int ps = (int)(nn - (long long)b * npc);
+            int oy = ps / Wq;
+            int ox = ps - oy * Wq;
+            if (nmem) {
+                const int mi = min(pass * per_pass + j, nmem - 1);
+                const int dy = mi / gm.pool_w;
+                oy = oy * gm.pool_h + dy;
+                ox = ox * gm.pool_w + (mi - dy * gm.pool_w);
+            }
+            bidx[j] = b;
+            pos[j] = ps;
+            iy0[j] = oy * gm.sh - gm.ph;
+            ix0[j] = ox * gm.sw - gm.pw;
+            inb[j] = b * gm.Cin * hw;
         }
-        bidx[j] = b;
-        pos[j] = ps;
-        iy0[j] = oy * gm.sh - gm.ph;
-        ix0[j] = ox * gm.sw - gm.pw;
-        inb[j] = b * gm.Cin * hw;
-    }
+    };
+    setup_tiles(0);
 
     const __amdgpu_buffer_rsrc_t rin =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((size_t)gm.B * gm.Cin * hw * 4), 0x00020000);
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
             _Pragma("unroll") for (int pt = 0; pt < 3; ++pt)                                          \
                 wa_[m][pt] = bload4(rwt, lane * 16 + (m * 3 + pt) * 1024, (S) * MT * 3 * 1024);       \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
-            if (nmem && j >= nmem) continue;   /* 1 x 3 windows: the fourth tile has no member (uniform branch) */ \
+            if (j >= ntile) continue;          /* windows with fewer members than tiles (uniform branch) */ \
             u32x4 bs_[3];                                                                             \
             split8(RAW[j], bs_);                                                                      \
             _Pragma("unroll") for (int m = 0; m < MT; ++m) { XMF6(wa_[m], bs_, acc[m][j]) }           \
@@ -177,21 +187,43 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
 
-    int s = s_begin;
-    XLOADB(raw0, s)
-    while (s + 2 < s_end) {
-        XLOADB(raw1, s + 1)
-        XCOMPUTE(raw0, s)
-        XLOADB(raw0, s + 2)
-        XCOMPUTE(raw1, s + 1)
-        s += 2;
-    }
-    if (s + 1 < s_end) {
-        XLOADB(raw1, s + 1)
-        XCOMPUTE(raw0, s)
-        XCOMPUTE(raw1, s + 1)
-    } else {
-        XCOMPUTE(raw0, s)
+    f32x4 best[MULTI ? MT : 1];   // running maximum over the window members
+#pragma unroll
+    for (int m = 0; m < (MULTI ? MT : 1); ++m) best[m] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+        if (pass > 0) {
+            setup_tiles(pass);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        int s = s_begin;
+        XLOADB(raw0, s)
+        while (s + 2 < s_end) {
+            XLOADB(raw1, s + 1)
+            XCOMPUTE(raw0, s)
+            XLOADB(raw0, s + 2)
+            XCOMPUTE(raw1, s + 1)
+            s += 2;
+        }
+        if (s + 1 < s_end) {
+            XLOADB(raw1, s + 1)
+            XCOMPUTE(raw0, s)
+            XCOMPUTE(raw1, s + 1)
+        } else {
+            XCOMPUTE(raw0, s)
+        }
+        if (MULTI) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < ntile)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) best[MULTI ? m : 0][r] = fmaxf(best[MULTI ? m : 0][r], acc[m][j][r]);
+        }
     }
 #undef XLOADB
 #undef XCOMPUTE
@@ -210,11 +242,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
             if (co >= gm.Cout) continue;
             const float bias = a.bias ? a.bias[co] : 0.f;
             if (nmem) {   // max over the window, then bias + ReLU (both monotone, so the order does not matter)
-                if (!valid[0]) continue;
-                float v = acc[m][0][r];
+                if (n0 + pcol >= ntot) continue;
+                float v;
+                if (MULTI) {
+                    v = best[MULTI ? m : 0][r];
+                } else {
+                    v = acc[m][0][r];
 #pragma unroll
-                for (int j = 1; j < 4; ++j)
-                    if (j < nmem) v = fmaxf(v, acc[m][j][r]);
+                    for (int j = 1; j < 4; ++j)
+                        if (j < nmem) v = fmaxf(v, acc[m][j][r]);
+                }
                 v += bias;
                 if (gm.relu) v = fmaxf(v, 0.f);
                 a.out[((size_t)bidx[0] * gm.Cout + co) * npc + pos[0]] = v;
@@ -243,22 +280,26 @@ static hipError_t launch_x_mt(const ConvGeom& g, const ConvArgs& a, hipStream_t 
     const long long ntot = pooled ? (long long)g.B * (g.Ho / g.pool_h) * (g.Wo / g.pool_w) : (long long)g.B * g.Ho * g.Wo;
     const int per_wg = pooled ? 64 : 256;
     dim3 grid((unsigned)((ntot + per_wg - 1) / per_wg), (unsigned)((g.mtiles + MT - 1) / MT), (unsigned)(g.ksplit > 1 ? g.ksplit : 1));
-    if (g.x_terms == 1) {
-        if (g.kx_inner)
-            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, true, 1>), grid, dim3(256), 0, s, g, a);
-        else
-            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, false, 1>), grid, dim3(256), 0, s, g, a);
-    } else if (g.x_terms == 3) {
-        if (g.kx_inner)
-            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, true, 3>), grid, dim3(256), 0, s, g, a);
-        else
-            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, false, 3>), grid, dim3(256), 0, s, g, a);
-    } else {
-        if (g.kx_inner)
-            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, true, 6>), grid, dim3(256), 0, s, g, a);
-        else
-            hipLaunchKernelGGL((conv_bf16x6_kernel<MT, false, 6>), grid, dim3(256), 0, s, g, a);
+    const bool multi = pooled && g.pool_h * g.pool_w > 4;
+#define X_LAUNCH(KX_, T_, M_) hipLaunchKernelGGL((conv_bf16x6_kernel<MT, KX_, T_, M_>), grid, dim3(256), 0, s, g, a)
+#define X_LAUNCH_T(T_)                                  \
+    if (multi) {                                        \
+        if (MT > 3) return hipErrorInvalidValue;        \
+        if (g.kx_inner) X_LAUNCH(true, T_, (MT <= 3));  \
+        else X_LAUNCH(false, T_, (MT <= 3));            \
+    } else {                                            \
+        if (g.kx_inner) X_LAUNCH(true, T_, false);      \
+        else X_LAUNCH(false, T_, false);                \
     }
+    if (g.x_terms == 1) {
+        X_LAUNCH_T(1)
+    } else if (g.x_terms == 3) {
+        X_LAUNCH_T(3)
+    } else {
+        X_LAUNCH_T(6)
+    }
+#undef X_LAUNCH_T
+#undef X_LAUNCH
     return hipGetLastError();
 }
 
@@ -271,7 +312,7 @@ bool conv_bf16x6_supported(const ConvGeom& g) {
 
 hipError_t launch_conv_bf16x6(const ConvGeom& g, const ConvArgs& a, hipStream_t s) {
     if (g.B <= 0) return hipSuccess;
-    if (g.pool_h * g.pool_w > 1 && (g.pool_h * g.pool_w > 4 || g.ksplit > 1 || g.accumulate || a.border ||
+    if (g.pool_h * g.pool_w > 1 && (g.pool_h * g.pool_w > 16 || g.ksplit > 1 || g.accumulate || a.border ||
                                     g.Ho < g.pool_h || g.Wo < g.pool_w))
         return hipErrorInvalidValue;
     switch (g.x_mt) {
@@ -313,7 +354,7 @@ void conv_bf16x6_geometry(ConvGeom& g) {
     // groups matter more than a fully used last group (Cout = 78: MT = 3 over 2 groups beats MT = 1 over 5).
     int best = 1;
     long long best_cost = -1;
-    for (int mt = 1; mt <= 4; ++mt) {
+    for (int mt = 1; mt <= (g.x_mt_cap > 0 ? g.x_mt_cap : 4); ++mt) {
         const long long cost = (long long)((g.mtiles + mt - 1) / mt) * (800 + 384 * mt);
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
