@@ -18,7 +18,7 @@ DTYPES = {"f32": KWS_DTYPE_F32, "fp32": KWS_DTYPE_F32, "float32": KWS_DTYPE_F32,
 # every symbol include/kws.h declares (tests check the library exports exactly these)
 EXPORTS = (
     "kws_create", "kws_destroy", "kws_load_weights", "kws_workspace_bytes", "kws_set_workspace", "kws_num_frames",
-    "kws_mfcc", "kws_mfcc_pcm16", "kws_forward", "kws_forward_wav", "kws_forward_pcm16", "kws_mfcc_windows", "kws_forward_windows", "kws_eval_batch", "kws_plan_name", "kws_profile_enable",
+    "kws_mfcc", "kws_mfcc_pcm16", "kws_forward", "kws_forward_wav", "kws_forward_pcm16", "kws_workspace_bytes_windows", "kws_mfcc_windows", "kws_forward_windows", "kws_eval_batch", "kws_plan_name", "kws_profile_enable",
     "kws_profile_read", "kws_last_error", "kws_abi_version",
 )
 
@@ -81,6 +81,8 @@ def load():
     lib.kws_forward.restype = ci
     lib.kws_forward_wav.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.kws_forward_wav.restype = ci
+    lib.kws_workspace_bytes_windows.argtypes = [vp, ci, ci, ci]
+    lib.kws_workspace_bytes_windows.restype = sz
     lib.kws_mfcc_windows.argtypes = [vp, vp, sz, ci, ci, ci, vp, vp]
     lib.kws_mfcc_windows.restype = ci
     lib.kws_forward_windows.argtypes = [vp, vp, sz, ci, ci, ci, vp, vp]
@@ -165,8 +167,10 @@ class Engine:
 
     # ---- workspace
     def _ensure_ws(self, batch, frames):
+        self._ensure_ws_bytes(int(self.lib.kws_workspace_bytes(self.handle, batch, frames)))
+
+    def _ensure_ws_bytes(self, need):
         import torch
-        need = int(self.lib.kws_workspace_bytes(self.handle, batch, frames))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
@@ -281,6 +285,7 @@ class Engine:
         stream, n_left, byte_off, count = self._stream_args(stream, window, shift, first, count)
         out = torch.empty((count, self.num_frames(window), self.desc.n_mels), dtype=torch.float32, device=stream.device)
         if count:
+            self._ensure_ws_bytes(int(self.lib.kws_workspace_bytes_windows(self.handle, window, shift, count)))
             check(self.lib.kws_mfcc_windows(self.handle, C.c_void_p(stream.data_ptr() + byte_off), n_left, window, shift,
                                             count, C.c_void_p(out.data_ptr()), self._stream()), "kws_mfcc_windows")
         return out
@@ -289,7 +294,7 @@ class Engine:
         import torch
         stream, n_left, byte_off, count = self._stream_args(stream, window, shift, first, count)
         if count:
-            self._ensure_ws(count, self.num_frames(window))
+            self._ensure_ws_bytes(int(self.lib.kws_workspace_bytes_windows(self.handle, window, shift, count)))
         if out is None:
             out = torch.empty((count, self.desc.n_labels), dtype=torch.float32, device=stream.device)
         if count:

@@ -252,6 +252,104 @@ hipError_t launch_frontend(const FrontendParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ streaming windows
+// Sliding windows of one long stream (reference dataset/dataset_utils.py:20-98) whose shift is a multiple of the hop share
+// their STFT: frame t of window n is centred on stream sample shift * n + 160 t, and for 2 <= t <= T - 3 its 480 samples
+// lie inside the window, so it is simply frame (shift / 160) * n + t of the stream taken as ONE long clip ("global"
+// frames G, computed once by frontend_kernel).  Only the two first and two last frames of a window touch its reflect
+// padding and are its own.  One workgroup per window: the four edge frames by a direct DFT on the vector units (4 x 128
+// bins x 480 terms), their mel / log rows, and a copy of the T - 4 shared rows out of G.
+__global__ __launch_bounds__(256) void window_edges_kernel(WindowEdgeParams p) {
+    __shared__ f32x4 y[FE_NFFT];            // y[i] = windowed sample i of the four edge frames
+    __shared__ f32x2 trig[FE_NFFT];         // cos, sin of 2 pi j / 480
+    __shared__ f32x4 part[2][2][FE_ROWS];   // [half of the sum][re / im][bin] x four frames
+    __shared__ f32x4 pw[FE_ROWS];           // power of the four frames
+    const int tid = threadIdx.x;
+    const int win = blockIdx.x;
+    const float* src = p.stream + (size_t)win * p.shift;
+    const int n = p.window, T = p.T;
+    const int ft[4] = {0, 1, T - 2, T - 1};
+    for (int i = tid; i < FE_NFFT; i += 256) {
+        trig[i] = p.trig[i];
+        const float hv = p.hann[i];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int sx = FE_HOP * ft[e] - FE_NFFT / 2 + i;   // reflect padding about the window's own ends
+            sx = sx < 0 ? -sx : sx;
+            sx = sx >= n ? 2 * (n - 1) - sx : sx;
+            sx = max(0, min(sx, n - 1));
+            v[e] = hv * src[sx];
+        }
+        y[i] = v;
+    }
+    __syncthreads();
+    {   // thread = (bin k, half of the 480 terms); re += y cos, im -= y sin
+        const int k = tid & (FE_ROWS - 1), half = tid >> 7;
+        f32x4 re = (f32x4){0.f, 0.f, 0.f, 0.f}, im = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int i0 = half * (FE_NFFT / 2);
+        int idx = (int)(((long long)k * i0) % FE_NFFT);
+        for (int i = i0; i < i0 + FE_NFFT / 2; ++i) {
+            const f32x2 cs = trig[idx];
+            const f32x4 v = y[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                re[e] = fmaf(v[e], cs[0], re[e]);
+                im[e] = fmaf(v[e], cs[1], im[e]);
+            }
+            idx += k;
+            idx = idx >= FE_NFFT ? idx - FE_NFFT : idx;
+        }
+        part[half][0][k] = re;
+        part[half][1][k] = im;
+    }
+    __syncthreads();
+    if (tid < FE_ROWS) {
+        const f32x4 re = part[0][0][tid] + part[1][0][tid], im = part[0][1][tid] + part[1][1][tid];
+        pw[tid] = re * re + im * im;
+    }
+    __syncthreads();
+    float* dst = p.feat + (size_t)win * T * p.n_mels;
+    for (int o = tid; o < 4 * p.n_mels; o += 256) {
+        const int e = o / p.n_mels, f = o - e * p.n_mels;
+        const float* wrow = p.melw + f * FE_ROWS;
+        float v = 0.f;
+        for (int k = p.mel_lo[f]; k < p.mel_hi[f]; ++k) v = fmaf(wrow[k], pw[k][e], v);
+        const float lg = v >= 1e-30f ? __logf(v) : (v > 0.f ? logf(v) : v);
+        dst[ft[e] * p.n_mels + f] = 2.0f * lg;
+    }
+    // shared rows 2 .. T - 3 are rows g0 + 2 .. of G, contiguous in both tensors
+    const size_t g0 = (size_t)win * (p.shift / FE_HOP);
+    const float* grow = p.global_feat + (g0 + 2) * p.n_mels;
+    float* drow = dst + 2 * p.n_mels;
+    const int ncopy = (T - 4) * p.n_mels;
+    if (((p.n_mels * 2) & 3) == 0 && (((g0 + 2) * p.n_mels) & 3) == 0 && ((T * p.n_mels) & 3) == 0) {
+        for (int i = tid; i < ncopy / 4; i += 256)
+            reinterpret_cast<f32x4*>(drow)[i] = reinterpret_cast<const f32x4*>(grow)[i];
+        for (int i = (ncopy & ~3) + tid; i < ncopy; i += 256) drow[i] = grow[i];
+    } else {
+        for (int i = tid; i < ncopy; i += 256) drow[i] = grow[i];
+    }
+}
+
+hipError_t launch_window_edges(const WindowEdgeParams& p, hipStream_t s) {
+    if (p.n_windows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(window_edges_kernel, dim3((unsigned)p.n_windows), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// Host: plain periodic Hann window and the unit circle in 480 steps (double-precision trig).
+void build_edge_tables(std::vector<float>& hann, std::vector<float>& trig) {
+    hann.resize(FE_NFFT);
+    trig.resize(2 * FE_NFFT);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int i = 0; i < FE_NFFT; ++i) {
+        hann[i] = (float)(0.5 - 0.5 * std::cos(two_pi * i / FE_NFFT));
+        trig[2 * i] = (float)std::cos(two_pi * i / FE_NFFT);
+        trig[2 * i + 1] = (float)std::sin(two_pi * i / FE_NFFT);
+    }
+}
+
 // Host: packed A operands and the Hann table.
 //   dft float4 index ((w*FE_GROUPS + grp)*4 + mt)*64 + lane, component q:
 //     row r = 16 mt + (lane & 15); bin k = 2 r + (w & 1); column j = 4 (4 grp + q) + (lane >> 4) + 1  (1..120)

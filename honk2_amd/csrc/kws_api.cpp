@@ -80,7 +80,7 @@ struct kws_handle {
     LwMode lw_mode = LW_TILED;
 
     // front end
-    DevMem dft, hann, melw, mel_lo, mel_hi;
+    DevMem dft, hann, melw, mel_lo, mel_hi, edge_hann, edge_trig;
     int mel_maxw = 0;
 
     // parameters
@@ -169,6 +169,10 @@ int setup_frontend(kws_handle* h) {
     int rc;
     if ((rc = h->dft.upload(tab.data(), tab.size() * sizeof(float)))) return rc;
     if ((rc = h->hann.upload(hann.data(), hann.size() * sizeof(float)))) return rc;
+    std::vector<float> ehann, etrig;
+    build_edge_tables(ehann, etrig);
+    if ((rc = h->edge_hann.upload(ehann.data(), ehann.size() * sizeof(float)))) return rc;
+    if ((rc = h->edge_trig.upload(etrig.data(), etrig.size() * sizeof(float)))) return rc;
     if ((rc = h->melw.upload(wts.data(), wts.size() * sizeof(float)))) return rc;
     if ((rc = h->mel_lo.upload(lo.data(), lo.size() * sizeof(int)))) return rc;
     if ((rc = h->mel_hi.upload(hi.data(), hi.size() * sizeof(int)))) return rc;
@@ -918,18 +922,66 @@ static int check_windows(size_t n_stream, int window, int shift, int n_windows) 
     return KWS_OK;
 }
 
+// Windows whose shift and length are multiples of the hop share all but their four edge frames with the stream's own
+// frames; worth it when the shared rows outnumber the stream's rows (i.e. the windows overlap).
+static bool windows_share_frames(int window, int shift, int n_windows) {
+    if (shift % FE_HOP || window % FE_HOP || window <= FE_NFFT) return false;
+    const long long T = 1 + window / FE_HOP, rows_g = (long long)(n_windows - 1) * (shift / FE_HOP) + T;
+    return n_windows >= 4 && T >= 8 && 2 * rows_g <= (long long)n_windows * (T - 4);
+}
+static size_t global_feat_bytes(const kws_handle* h, int window, int shift, int n_windows) {
+    const size_t rows = (size_t)std::max(n_windows - 1, 0) * (size_t)(shift / FE_HOP) + 1 + window / FE_HOP;
+    return align256(rows * h->d.n_mels * sizeof(float));
+}
+
+// features of all windows; gbuf: device scratch of global_feat_bytes() for the shared-frame path, or nullptr
+static int mfcc_windows_impl(kws_handle* h, const float* d_stream, int window, int shift, int n_windows, float* d_feat,
+                             void* stream, float* gbuf) {
+    const bool no_share = std::getenv("KWS_WINDOWS_NO_SHARE") != nullptr;   // A/B and tests (read per call on purpose)
+    if (!gbuf || no_share || !windows_share_frames(window, shift, n_windows))
+        return mfcc_any(h, d_stream, nullptr, nullptr, 0.f, n_windows, window, d_feat, stream, shift);
+    if (!d_stream || !d_feat) return fail(KWS_EINVAL, "bad argument");
+    const long long covered = (long long)(n_windows - 1) * shift + window;
+    if (covered > 0x7fffffffLL) return fail(KWS_EINVAL, "stream too long for one call");
+    int rc = mfcc_any(h, d_stream, nullptr, nullptr, 0.f, 1, (int)covered, gbuf, stream);   // the stream as one clip
+    if (rc) return rc;
+    WindowEdgeParams p{d_stream, gbuf, d_feat, h->edge_hann.as<float>(), h->edge_trig.as<f32x2>(), h->melw.as<float>(),
+                       h->mel_lo.as<int>(), h->mel_hi.as<int>(), window, shift, n_windows, 1 + window / FE_HOP, h->d.n_mels};
+    HIP_TRY(launch_window_edges(p, static_cast<hipStream_t>(stream)));
+    return KWS_OK;
+}
+
+size_t kws_workspace_bytes_windows(const kws_handle* h, int window, int shift, int n_windows) {
+    if (!h || window < 1 || shift < 1 || n_windows < 0) return 0;
+    const size_t base = kws_workspace_bytes(h, n_windows, 1 + window / FE_HOP);
+    return base + (windows_share_frames(window, shift, n_windows) ? global_feat_bytes(h, window, shift, n_windows) : 0);
+}
+
 int kws_mfcc_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
                      float* d_feat, void* stream) {
+    if (!h) return fail(KWS_EINVAL, "null handle");
     int rc = check_windows(n_stream, window, shift, n_windows);
     if (rc) return rc;
-    return mfcc_any(h, d_stream, nullptr, nullptr, 0.f, n_windows, window, d_feat, stream, shift);
+    // the scratch for the stream's own frames comes from the head of the workspace when there is one that is big enough
+    float* gbuf = (h->ws && h->ws_bytes >= global_feat_bytes(h, window, shift, n_windows)) ? static_cast<float*>(h->ws) : nullptr;
+    return mfcc_windows_impl(h, d_stream, window, shift, n_windows, d_feat, stream, gbuf);
 }
 
 int kws_forward_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
                         float* d_logits, void* stream) {
+    if (!h || !d_stream || !d_logits) return fail(KWS_EINVAL, "bad argument");
     int rc = check_windows(n_stream, window, shift, n_windows);
     if (rc) return rc;
-    return forward_any(h, d_stream, nullptr, nullptr, 0.f, n_windows, window, d_logits, stream, shift);
+    if ((rc = finalize(h))) return rc;
+    const int T = 1 + window / FE_HOP;
+    const size_t fb = feat_bytes(h, n_windows, T), ab = act_bytes(h, n_windows, T);
+    if ((rc = check_ws(h, fb + ab))) return rc;
+    const size_t gb = global_feat_bytes(h, window, shift, n_windows);
+    float* feat = static_cast<float*>(h->ws);
+    float* gbuf = h->ws_bytes >= fb + ab + gb ? reinterpret_cast<float*>(static_cast<char*>(h->ws) + fb + ab) : nullptr;
+    if ((rc = mfcc_windows_impl(h, d_stream, window, shift, n_windows, feat, stream, gbuf))) return rc;
+    char* ws_act = ab ? static_cast<char*>(h->ws) + fb : nullptr;
+    return run_model(h, feat, n_windows, T, d_logits, ws_act, static_cast<hipStream_t>(stream));
 }
 
 int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target, int B, int64_t* d_stats,

@@ -39,6 +39,20 @@ struct FrontendParams {
     int mel_maxw;         // widest mel filter in bins (fast path keeps <= 16 weights in registers)
     long long clip_stride;   // samples between the starts of consecutive clips (n_samples for a packed batch)
 };
+// streaming windows whose shift is a multiple of the hop: edge frames + copy of the shared rows (frontend.hip)
+struct WindowEdgeParams {
+    const float* stream;        // the long waveform; window i starts at sample i * shift
+    const float* global_feat;   // (1 + n_stream / hop, n_mels): features of the stream taken as one clip
+    float* feat;                // (n_windows, T, n_mels)
+    const float* hann;          // (480) periodic Hann
+    const f32x2* trig;          // (480) cos, sin of 2 pi j / 480
+    const float* melw;
+    const int* mel_lo;
+    const int* mel_hi;
+    int window, shift, n_windows, T, n_mels;
+};
+hipError_t launch_window_edges(const WindowEdgeParams& p, hipStream_t s);
+void build_edge_tables(std::vector<float>& hann, std::vector<float>& trig);
 size_t frontend_lds_bytes(int T);
 hipError_t launch_frontend(const FrontendParams& p, hipStream_t s);
 void build_dft_table(std::vector<float>& dft, std::vector<float>& hann);  // host side, double precision trig

@@ -131,7 +131,11 @@ int kws_forward_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise,
 /* Streaming evaluation: window i of a long stream is d_stream[i*shift : i*shift + window] (window_size_ms / shift_size_ms of
  * the reference's streaming datasets, in samples); every window takes the usual path (its own reflect padding included,
  * exactly as if it had been copied out), but the windows are read in place -- no (n_windows, window) batch is built.
- * (n_windows - 1) * shift + window must not exceed n_stream. */
+ * (n_windows - 1) * shift + window must not exceed n_stream.
+ * When window and shift are multiples of the hop and the windows overlap, all but the first two and last two frames of a
+ * window are frames of the stream itself: they are computed once for the whole stream and only the edge frames per window
+ * (needs kws_workspace_bytes_windows() of workspace; with less, every window is transformed on its own). */
+size_t kws_workspace_bytes_windows(const kws_handle* h, int window, int shift, int n_windows);
 int kws_mfcc_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
                      float* d_feat, void* stream);
 int kws_forward_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
