@@ -299,37 +299,47 @@ __global__ __launch_bounds__(256, 1) void res8x_kernel(Res8xParams p) {
         koff[s] = k < 9 ? (k / 3) * FS + (k - 3 * (k / 3)) : 0;
     }
 
-    for (int clip = blockIdx.x; clip < p.B; clip += gridDim.x) {
-        __syncthreads();  // previous clip's tail has consumed red/mvec and the maps
-
-        // ---- stage the (101, 40) feature map as fp32 with a zero top row / left column
-        {
-            const f32x4* f4 = reinterpret_cast<const f32x4*>(p.feat + (size_t)clip * p.T * p.F);
-            f32x4 v[4];
+    // The (101, 40) feature map of a clip is staged as fp32 with a zero top row / left column.  Only conv_0 reads it, so the
+    // NEXT clip's map is requested (into registers) while conv_0 of the current clip runs and is written to LDS right after
+    // it: a clip never waits for its own features.
+    auto feat_load = [&](int clip, f32x4 (&v)[4]) {
+        const f32x4* f4 = reinterpret_cast<const f32x4*>(p.feat + (size_t)clip * p.T * p.F);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int q4 = it * 256 + tid;
-                if (q4 < 1010) v[it] = f4[q4];
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int q4 = it * 256 + tid;
-                if (q4 < 1010) {
-                    const int idx = 4 * q4;
-                    const int cell = idx + idx / 40 + FS + 1;
-                    feat_s[cell] = v[it][0];
-                    feat_s[cell + 1] = v[it][1];
-                    feat_s[cell + 2] = v[it][2];
-                    feat_s[cell + 3] = v[it][3];
-                }
-            }
-            if (tid < FS) feat_s[tid] = 0.f;
-            if (tid < 101) feat_s[(tid + 1) * FS] = 0.f;
+        for (int it = 0; it < 4; ++it) {
+            const int q4 = it * 256 + tid;
+            v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (q4 < 1010) v[it] = f4[q4];
         }
-        __syncthreads();
+    };
+    auto feat_store = [&](const f32x4 (&v)[4]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q4 = it * 256 + tid;
+            if (q4 < 1010) {
+                const int idx = 4 * q4;
+                const int cell = idx + idx / 40 + FS + 1;
+                feat_s[cell] = v[it][0];
+                feat_s[cell + 1] = v[it][1];
+                feat_s[cell + 2] = v[it][2];
+                feat_s[cell + 3] = v[it][3];
+            }
+        }
+    };
+    if ((int)blockIdx.x < p.B) {
+        f32x4 v0[4];
+        feat_load(blockIdx.x, v0);
+        feat_store(v0);
+        if (tid < FS) feat_s[tid] = 0.f;
+        if (tid < 101) feat_s[(tid + 1) * FS] = 0.f;
+    }
+
+    for (int clip = blockIdx.x; clip < p.B; clip += gridDim.x) {
+        __syncthreads();  // previous clip's tail has consumed red/mvec and the maps; this clip's features are in place
+        const int clip_next = clip + (int)gridDim.x;
 
         // ---- conv_0 + ReLU + AvgPool(4,3): fp32-input MFMA (K = 9), result in accumulator layout = prev_x
         f32x4 prev[5][3], prevx;
+        f32x4 vnext[4];
         {
             float a0[3][3];
 #pragma unroll
@@ -338,6 +348,8 @@ __global__ __launch_bounds__(256, 1) void res8x_kernel(Res8xParams p) {
                 for (int s = 0; s < 3; ++s) a0[m][s] = p.w0a[(m * 3 + s) * 64 + lane];
             const float ax0 = p.w0a[(mx * 3 + 0) * 64 + lane], ax1 = p.w0a[(mx * 3 + 1) * 64 + lane],
                         ax2 = p.w0a[(mx * 3 + 2) * 64 + lane];
+            // after the (L2-resident) conv_0 weights: vector loads retire in order
+            if (clip_next < p.B) feat_load(clip_next, vnext);
             const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
@@ -395,6 +407,7 @@ __global__ __launch_bounds__(256, 1) void res8x_kernel(Res8xParams p) {
             for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + (16 * m + 4 * g) * 2, prev[j][m]);
         if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, prevx);
         __syncthreads();
+        if (clip_next < p.B) feat_store(vnext);   // every wave is past conv_0: the staging area is free
 
         x_layer<TERMS, false, false>(p, c, 0, clip, prev, prevx);
         x_layer<TERMS, true, false>(p, c, 1, clip, prev, prevx);
