@@ -92,10 +92,13 @@ struct kws_handle {
     DevMem bn_mean, bn_rstd;               // (n_layers, C) each: the LAST layer's BN is applied after the spatial mean
     DevMem out_w, out_b;
     // fused res8
-    DevMem r8_w0a, r8_apk, r8_bn, r8_zcells, r8x_apk;
+    DevMem r8_w0a, r8_apk, r8_bn, r8_zcells, r8x_apk, r8h_apk, r8h_bn;
     std::vector<float> r8_apk_host;
-    std::vector<unsigned short> r8x_apk_host;
-    bool res8_fp32_mfma = false;   // KWS_RES8_IMPL=fp32: use the fp32-input MFMA kernel instead of the bf16x6 one
+    std::vector<unsigned short> r8x_apk_host, r8h_apk_host;
+    float r8h_scale[R8_LAYERS] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // 2^S per layer (fp16 path)
+    // fused res8 kernel: 0 = fp16 three-term products (default), 1 = bf16 six-term (KWS_RES8_IMPL=bf16x6; also what the
+    // reduced-precision dtypes use), 2 = fp32-input MFMA (KWS_RES8_IMPL=fp32)
+    int res8_impl = 0;
     // CNN
     std::vector<ConvLayer> cconv;          // conv_0 [, conv_1]
     std::vector<ConvLayer> clin;           // lin_0, dnn_0, dnn_1, lin_1 (present ones, in order)
@@ -230,8 +233,10 @@ int build_resnet(kws_handle* h) {
     if (h->res8_eligible) {
         h->r8_apk_host.assign(R8_APK_FLOATS, 0.f);
         h->r8x_apk_host.assign(R8X_APK_SHORTS, 0);
+        h->r8h_apk_host.assign(R8H_APK_SHORTS, 0);
         const char* impl = std::getenv("KWS_RES8_IMPL");
-        h->res8_fp32_mfma = impl && std::strcmp(impl, "fp32") == 0;
+        h->res8_impl = impl && std::strcmp(impl, "fp32") == 0 ? 2 : (impl && std::strcmp(impl, "bf16x6") == 0 ? 1 : 0);
+        if (d.dtype != KWS_DTYPE_F32 && h->res8_impl == 0) h->res8_impl = 1;   // bf16x3 / bf16 modes live in the bf16 kernel
     }
     return KWS_OK;
 }
@@ -382,6 +387,11 @@ int finalize(kws_handle* h) {
             if ((rc = h->r8_bn.upload(tab.data(), tab.size() * 4))) return rc;
             if ((rc = h->r8_apk.upload(h->r8_apk_host.data(), h->r8_apk_host.size() * 4))) return rc;
             if ((rc = h->r8x_apk.upload(h->r8x_apk_host.data(), h->r8x_apk_host.size() * 2))) return rc;
+            if ((rc = h->r8h_apk.upload(h->r8h_apk_host.data(), h->r8h_apk_host.size() * 2))) return rc;
+            std::vector<float> tabh = tab;   // fp16 path: odd layers (index 0, 2, 4) fold 2^-S into the BatchNorm scale
+            for (int i = 0; i < R8_LAYERS; i += 2)
+                for (int c = 0; c < 48; ++c) tabh[(size_t)i * 96 + c] /= h->r8h_scale[i];
+            if ((rc = h->r8h_bn.upload(tabh.data(), tabh.size() * 4))) return rc;
             std::vector<int> zc(1024);
             build_res8_zero_cells(zc.data());
             if ((rc = h->r8_zcells.upload(zc.data(), zc.size() * sizeof(int)))) return rc;
@@ -673,7 +683,15 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
     if (h->plan == PLAN_RESNET) {
         if (use_fused(h, T)) {
             static const int dbg = std::getenv("KWS_R8_DEBUG") ? std::atoi(std::getenv("KWS_R8_DEBUG")) : 0;
-            if (h->res8_fp32_mfma) {
+            if (h->res8_impl == 0) {
+                h->last_plan = "res8_fused";
+                Res8hParams p{};
+                p.feat = feat; p.logits = logits; p.w0a = h->r8_w0a.as<float>(); p.apk2 = h->r8h_apk.p;
+                p.bn_tab = h->r8h_bn.as<float>(); p.out_w = h->out_w.as<float>(); p.out_b = h->out_b.as<float>();
+                for (int i = 0; i < R8_LAYERS; ++i) p.inv_scale[i] = 1.0f / h->r8h_scale[i];
+                p.B = B; p.T = T; p.F = h->d.freq; p.n_labels = h->d.n_labels; p.debug = dbg;
+                HIP_TRY(launch_res8h(p, std::min(B, 256), s));
+            } else if (h->res8_impl == 2) {
                 h->last_plan = "res8_fused_fp32mfma";
                 Res8Params p{feat, logits, h->r8_w0a.as<float>(), h->r8_apk.as<f32x4>(), h->r8_bn.as<float>(),
                              h->r8_zcells.as<int>(), h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq,
@@ -681,7 +699,7 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 static const int grid_env = std::getenv("KWS_R8_GRID") ? std::atoi(std::getenv("KWS_R8_GRID")) : 512;
                 HIP_TRY(launch_res8(p, std::min(B, grid_env), s));
             } else {
-                h->last_plan = "res8_fused";
+                h->last_plan = "res8_fused_bf16x6";
                 Res8xParams p{feat, logits, h->r8_w0a.as<float>(), h->r8x_apk.p, h->r8_bn.as<float>(),
                               h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq, h->d.n_labels, dbg,
                               dtype_terms(h->d.dtype)};
@@ -793,6 +811,9 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
                 } else {
                     pack_res8_layer(src, h->r8_apk_host.data() + (size_t)(idx - 1) * R8_GROUPS * 3 * 64 * 4);
                     pack_res8x_layer(src, h->r8x_apk_host.data() + (size_t)(idx - 1) * R8X_KSTEPS * 3 * 3 * 64 * 8);
+                    h->r8h_scale[idx - 1] = res8h_weight_scale(src, n);
+                    pack_res8h_layer(src, h->r8h_scale[idx - 1],
+                                     h->r8h_apk_host.data() + (size_t)(idx - 1) * R8X_KSTEPS * 3 * 2 * 64 * 8);
                 }
             }
         } else if (std::sscanf(name.c_str(), "layers.bn_%d.%31s", &idx, field) == 2) {

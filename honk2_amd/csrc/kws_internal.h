@@ -104,6 +104,26 @@ size_t res8x_lds_bytes();
 hipError_t launch_res8x(const Res8xParams& p, int grid, hipStream_t s);
 void pack_res8x_layer(const float* w /*45x45x3x3*/, unsigned short* dst /*R8X_KSTEPS*3*3*64*8*/);
 
+// ---------------------------------------------------------------- fused res8, fp16 three-term matrix path (res8_f16x3.hip)
+constexpr size_t R8H_APK_SHORTS = (size_t)R8_LAYERS * R8X_KSTEPS * 3 * 2 * 64 * 8;
+
+struct Res8hParams {
+    const float* feat;    // (B, 101, 40)
+    float* logits;        // (B, n_labels)
+    const float* w0a;     // conv_0 weight as fp32 A fragments (pack_res8_conv0)
+    const void* apk2;     // conv_1..6 weights * 2^S split into two fp16 parts, fragment order (pack_res8h_layer)
+    const float* bn_tab;  // (6, 96): per layer scale[48], shift[48]; the scale of ODD layers carries the layer's 2^-S
+    const float* out_w;   // (n_labels, 45)
+    const float* out_b;   // (n_labels)
+    float inv_scale[R8_LAYERS];   // 2^-S per layer
+    int B, T, F, n_labels;
+    int debug;            // timing experiments only: 1 skip conv_0, 2 skip the MFMA loop
+};
+size_t res8h_lds_bytes();
+hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s);
+float res8h_weight_scale(const float* w /*45x45x3x3*/, size_t n);
+void pack_res8h_layer(const float* w /*45x45x3x3*/, float scale, unsigned short* dst /*R8X_KSTEPS*3*2*64*8*/);
+
 // ---------------------------------------------------------------- layer-wise kernels (layerwise.hip)
 struct ConvGeom {
     int B;                 // clips in this launch

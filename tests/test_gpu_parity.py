@@ -195,22 +195,30 @@ def test_tiled_resnet_on_odd_shapes_and_unsupported_widths(torch_cuda):
         assert (got.argmax(1) == want.argmax(1)).all()
 
 
-def test_res8_fp32_mfma_kernel_agrees_with_bf16x6_kernel(torch_cuda, monkeypatch):
-    """Two independent fused kernels: the default one forms fp32-accurate products from six bf16 MFMA terms, the
-    other (KWS_RES8_IMPL=fp32) uses the fp32-input MFMA.  Both must match the reference and each other."""
+def test_three_fused_res8_kernels_agree_and_are_fp32_accurate(torch_cuda, monkeypatch):
+    """Three independent fused kernels: the default forms fp32-accurate products from three fp16 MFMA terms (two-part fp16
+    splits, weights pre-scaled by a power of two), KWS_RES8_IMPL=bf16x6 from six bf16 terms, KWS_RES8_IMPL=fp32 uses the
+    fp32-input MFMA.  All must match the reference and each other, and the split-product kernels must be at least as close
+    to a float64 evaluation as an fp32 implementation (torch CPU) is -- they are not reduced-precision modes."""
     torch = torch_cuda
+    from oracle import models
     tag, name, cfg, sd, feats, z = load_golden_model("model_resnet__res8.npz")
     x = torch.from_numpy(feats).cuda()
-    a = _build(torch, name, cfg, sd)
-    ya = a(x).cpu().numpy()
-    assert a.plan_name() == "res8_fused"
-    monkeypatch.setenv("KWS_RES8_IMPL", "fp32")
-    b = _build(torch, name, cfg, sd)
-    yb = b(x).cpu().numpy()
-    assert b.plan_name() == "res8_fused_fp32mfma"
-    for y in (ya, yb):
+    ys = {}
+    for impl, plan in (("", "res8_fused"), ("bf16x6", "res8_fused_bf16x6"), ("fp32", "res8_fused_fp32mfma")):
+        if impl:
+            monkeypatch.setenv("KWS_RES8_IMPL", impl)
+        m = _build(torch, name, cfg, sd)
+        ys[plan] = m(x).cpu().numpy()
+        assert m.plan_name() == plan
+    for y in ys.values():
         assert np.abs(y - z["logits"]).max() < LOGIT_TOL and (y.argmax(1) == z["logits"].argmax(1)).all()
-    assert np.abs(ya - yb).max() < 2e-5
+    assert np.abs(ys["res8_fused"] - ys["res8_fused_bf16x6"]).max() < 2e-5
+    assert np.abs(ys["res8_fused"] - ys["res8_fused_fp32mfma"]).max() < 2e-5
+    exact = models.forward_numpy(name, cfg, sd, feats, np.float64)
+    err_fp32_impl = np.abs(models.forward_torch(name, cfg, sd, feats).numpy() - exact).max()
+    for plan in ("res8_fused", "res8_fused_bf16x6"):
+        assert np.abs(ys[plan] - exact).max() <= 2.0 * err_fp32_impl + 1e-7, (plan, np.abs(ys[plan] - exact).max(), err_fp32_impl)
 
 
 def test_wav_to_logits_end_to_end(torch_cuda):
