@@ -36,7 +36,8 @@ constexpr int PART_B = 96;
 constexpr int MAP_BYTES = 384 * CELL_B;               // 73 728
 constexpr int FS = 41;                                // staged feature row stride (fp32 words)
 constexpr int FEAT_BYTES = ((102 * FS * 4 + 15) / 16) * 16;
-constexpr int RED_OFF = MAP_BYTES + FEAT_BYTES;       // fp32 words from here on
+static_assert(FEAT_BYTES <= MAP_BYTES, "the feature map is staged inside the (idle) activation map");
+constexpr int RED_OFF = MAP_BYTES;                    // fp32 words from here on
 constexpr int BNT_WORDS = R8_LAYERS * 96;
 constexpr int X_LDS_BYTES = RED_OFF + (4 * 48 + 48 + BNT_WORDS) * 4;
 constexpr int KSTEPS = R8X_KSTEPS;                    // 14
@@ -83,8 +84,7 @@ struct XCtx {
 };
 
 struct AFrags {
-    u32x4 a[3][2];   // [channel tile][part]
-    u32x4 ax[2];     // extra tile's channel tile
+    u32x4 a[3][2];   // [channel tile][part]; the extra position tile uses a[mx] (mx is wave-uniform)
 };
 struct BFrag {
     u32x4 p[2];      // the two fp16 parts of one position tile's B fragment
@@ -103,8 +103,7 @@ __device__ __forceinline__ void load_a(AFrags& f, const u32x4* A, int s, int mx)
     for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) f.a[m][pt] = As[(m * 2 + pt) * 64];
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) f.ax[pt] = As[(mx * 2 + pt) * 64];
+    (void)mx;
 }
 __device__ __forceinline__ void load_b(BFrag& b, const char* lds, int addr) {
 #pragma unroll
@@ -124,7 +123,9 @@ __device__ __forceinline__ void load_b(BFrag& b, const char* lds, int addr) {
             if (j < 5) {                                                              \
                 _Pragma("unroll") for (int m = 0; m < 3; ++m) { MF6(AF.a[m], bcur.p, acc[j][m]) } \
             } else {                                                                  \
-                MF6(AF.ax, bcur.p, accx)                                              \
+                if (c.mx == 0) { MF6(AF.a[0], bcur.p, accx) }                         \
+                else if (c.mx == 1) { MF6(AF.a[1], bcur.p, accx) }                    \
+                else { MF6(AF.a[2], bcur.p, accx) }                                   \
             }                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                        \
         }                                                                             \
@@ -158,6 +159,7 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
         X_STEP(fa1, o1, o2)                                                                                        \
     }
     if (!(p.debug & 2)) {
+#pragma unroll 1   // unrolled, the scheduler hoists weight loads of later steps and spills at 256 registers
         for (int s = 0; s < KSTEPS; s += 2) X_PAIR(s)
     }
 #undef X_PAIR
@@ -242,11 +244,14 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
 
 size_t res8h_lds_bytes() { return (size_t)X_LDS_BYTES; }
 
-__global__ __launch_bounds__(256, 1) void res8h_kernel(Res8hParams p) {
+// Two workgroups (two clips) per CU: 77 KB of LDS and <= 256 registers each.  While one is in an epilogue, in conv_0 or
+// waiting for its features, the other's waves keep the matrix pipe busy -- the overlap a single workgroup with one wave
+// per SIMD cannot have.
+__global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     XCtx c;
     c.lds = ldsb;
-    float* feat_s = reinterpret_cast<float*>(ldsb + MAP_BYTES);
+    float* feat_s = reinterpret_cast<float*>(ldsb);   // conv_0's input is staged where the activation map will be
     c.red = reinterpret_cast<float*>(ldsb + RED_OFF);
     c.mvec = c.red + 4 * 48;
     float* bnt = c.mvec + 48;
@@ -261,10 +266,8 @@ __global__ __launch_bounds__(256, 1) void res8h_kernel(Res8hParams p) {
     c.mx = c.w < 2 ? c.w : 2;
     const int w = c.w, g = c.g, pcol = c.pcol, mx = c.mx, lane = c.lane;
 
-    for (int i = tid; i < MAP_BYTES / 4; i += 256) reinterpret_cast<unsigned*>(ldsb)[i] = 0u;   // zero halo, for good
     for (int i = tid; i < BNT_WORDS; i += 256) bnt[i] = p.bn_tab[i];
 
-    int lb[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int nt = j < 5 ? 5 * w + j : 20;
@@ -273,58 +276,59 @@ __global__ __launch_bounds__(256, 1) void res8h_kernel(Res8hParams p) {
         const int y = nn / W8_W;
         const int x = nn - y * W8_W;
         c.qb[j] = ((y + 1) * R8_RS + x + 1) * CELL_B;
-        lb[j] = 4 * y * FS + 3 * x;
     }
     c.xvalid = w < 3 && (16 * 20 + pcol) < R8_NPOS;
-    int koff[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int k = 4 * s + g;
-        koff[s] = k < 9 ? (k / 3) * FS + (k - 3 * (k / 3)) : 0;
-    }
-
-    // The (101, 40) feature map of a clip is staged as fp32 with a zero top row / left column.  Only conv_0 reads it, so the
-    // NEXT clip's map is requested (into registers) while conv_0 of the current clip runs and is written to LDS right after
-    // it: a clip never waits for its own features.
-    auto feat_load = [&](int clip, f32x4 (&v)[4]) {
-        const f32x4* f4 = reinterpret_cast<const f32x4*>(p.feat + (size_t)clip * p.T * p.F);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int q4 = it * 256 + tid;
-            v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (q4 < 1010) v[it] = f4[q4];
-        }
-    };
-    auto feat_store = [&](const f32x4 (&v)[4]) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int q4 = it * 256 + tid;
-            if (q4 < 1010) {
-                const int idx = 4 * q4;
-                const int cell = idx + idx / 40 + FS + 1;
-                feat_s[cell] = v[it][0];
-                feat_s[cell + 1] = v[it][1];
-                feat_s[cell + 2] = v[it][2];
-                feat_s[cell + 3] = v[it][3];
-            }
-        }
-    };
-    if ((int)blockIdx.x < p.B) {
-        f32x4 v0[4];
-        feat_load(blockIdx.x, v0);
-        feat_store(v0);
-        if (tid < FS) feat_s[tid] = 0.f;
-        if (tid < 101) feat_s[(tid + 1) * FS] = 0.f;
-    }
 
     for (int clip = blockIdx.x; clip < p.B; clip += gridDim.x) {
-        __syncthreads();  // previous clip's tail has consumed red/mvec and the maps; this clip's features are in place
-        const int clip_next = clip + (int)gridDim.x;
+        __syncthreads();  // previous clip's tail has consumed red/mvec and the map
+
+        // ---- stage the (101, 40) feature map as fp32 with a zero top row / left column, inside the idle map region
+        {
+            const f32x4* f4 = reinterpret_cast<const f32x4*>(p.feat + (size_t)clip * p.T * p.F);
+            f32x4 v[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q4 = it * 256 + tid;
+                v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (q4 < 1010) v[it] = f4[q4];
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q4 = it * 256 + tid;
+                if (q4 < 1010) {
+                    const int idx = 4 * q4;
+                    const int cell = idx + idx / 40 + FS + 1;
+                    feat_s[cell] = v[it][0];
+                    feat_s[cell + 1] = v[it][1];
+                    feat_s[cell + 2] = v[it][2];
+                    feat_s[cell + 3] = v[it][3];
+                }
+            }
+            if (tid < FS) feat_s[tid] = 0.f;
+            if (tid < 101) feat_s[(tid + 1) * FS] = 0.f;
+        }
+        __syncthreads();
 
         // ---- conv_0 + ReLU + AvgPool(4,3): fp32-input MFMA (K = 9), result in accumulator layout = prev_x
         f32x4 prev[5][3], prevx;
-        f32x4 vnext[4];
         {
+            // staged-feature offsets of this lane's pooling windows and taps (conv_0 only: recomputed per clip so that they
+            // do not occupy registers during the layers)
+            int lb[6], koff[3];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int nt = j < 5 ? 5 * w + j : 20;
+                const int n = 16 * nt + pcol;
+                const int nn = n < R8_NPOS ? n : R8_NPOS - 1;
+                const int y = nn / W8_W;
+                const int x = nn - y * W8_W;
+                lb[j] = 4 * y * FS + 3 * x;
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int k = 4 * s + g;
+                koff[s] = k < 9 ? (k / 3) * FS + (k - 3 * (k / 3)) : 0;
+            }
             float a0[3][3];
 #pragma unroll
             for (int m = 0; m < 3; ++m)
@@ -332,8 +336,6 @@ __global__ __launch_bounds__(256, 1) void res8h_kernel(Res8hParams p) {
                 for (int s = 0; s < 3; ++s) a0[m][s] = p.w0a[(m * 3 + s) * 64 + lane];
             const float ax0 = p.w0a[(mx * 3 + 0) * 64 + lane], ax1 = p.w0a[(mx * 3 + 1) * 64 + lane],
                         ax2 = p.w0a[(mx * 3 + 2) * 64 + lane];
-            // after the (L2-resident) conv_0 weights: vector loads retire in order
-            if (clip_next < p.B) feat_load(clip_next, vnext);
             const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
@@ -384,14 +386,17 @@ __global__ __launch_bounds__(256, 1) void res8h_kernel(Res8hParams p) {
                 prevx = sx * (1.0f / 12.0f);
             }
         }
-        // the maps are idle here (the previous clip finished behind the barrier at the top of the loop)
+        // every wave is done with the staged features: turn the region back into an all-zero map (halo cells included), then
+        // write the pooled conv_0 output into its interior
+        __syncthreads();
+        for (int i = tid; i < MAP_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(ldsb)[i] = (u32x4){0u, 0u, 0u, 0u};
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
             for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + (16 * m + 4 * g) * 2, prev[j][m]);
         if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, prevx);
         __syncthreads();
-        if (clip_next < p.B) feat_store(vnext);   // every wave is past conv_0: the staging area is free
 
         x_layer<false, false>(p, c, 0, clip, prev, prevx);
         x_layer<true, false>(p, c, 1, clip, prev, prevx);
