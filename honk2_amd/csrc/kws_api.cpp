@@ -690,7 +690,8 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 p.bn_tab = h->r8h_bn.as<float>(); p.out_w = h->out_w.as<float>(); p.out_b = h->out_b.as<float>();
                 for (int i = 0; i < R8_LAYERS; ++i) p.inv_scale[i] = 1.0f / h->r8h_scale[i];
                 p.B = B; p.T = T; p.F = h->d.freq; p.n_labels = h->d.n_labels; p.debug = dbg;
-                HIP_TRY(launch_res8h(p, std::min(B, 2 * h->n_cu), s));
+                static const int r8_wgs = std::getenv("KWS_R8_WGS_PER_CU") ? std::atoi(std::getenv("KWS_R8_WGS_PER_CU")) : 2;
+                HIP_TRY(launch_res8h(p, std::min(B, r8_wgs * h->n_cu), s));
             } else if (h->res8_impl == 2) {
                 h->last_plan = "res8_fused_fp32mfma";
                 Res8Params p{feat, logits, h->r8_w0a.as<float>(), h->r8_apk.as<f32x4>(), h->r8_bn.as<float>(),

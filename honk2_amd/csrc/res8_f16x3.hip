@@ -245,8 +245,12 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
 size_t res8h_lds_bytes() { return (size_t)X_LDS_BYTES; }
 
 // Two workgroups (two clips) per CU: 77 KB of LDS and <= 256 registers each.  While one is in an epilogue, in conv_0 or
-// waiting for its features, the other's waves keep the matrix pipe busy -- the overlap a single workgroup with one wave
-// per SIMD cannot have.
+// waiting for its features, the other's waves use the matrix pipe -- the overlap a single workgroup with one wave per SIMD
+// cannot have.  Measured (KWS_R8_WGS_PER_CU=1|2 with this very kernel): 21.9 -> 16.9 ms per 65 536 clips; the one-wave-
+// per-SIMD, 502-register build of the same code took 18.0 ms.  The overlap is partial because at 256 registers hipcc emits
+// VGPR-accumulator MFMAs, which one wave can only issue at half rate (tools/mfma_dep_probe.cpp): alone in its k-loop a
+// workgroup does not fill the pipe.  Forcing AGPR accumulators splits the budget 128 / 128 and spills (18.2 ms); a
+// start-up stagger of the second workgroup changes nothing.
 __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     XCtx c;
