@@ -31,11 +31,12 @@ namespace kws {
 
 namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TILE_P = T3_TILE_P;   // output positions per workgroup
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     const bf16x2 v = {(__bf16)a, (__bf16)b};
@@ -84,30 +85,56 @@ __device__ __forceinline__ int layout_cell(int b, int y, int x, int ld, int H, i
     return (((b << (2 * ld)) + sub) * Hs + (y >> ld)) * Ws + (x >> ld);
 }
 
+// two fp16 parts (x = h + l to 22 bits) of four fp32 values
+__device__ __forceinline__ void split4_f16(f32x4 x, u32x2 (&out)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f16x2 h = {(_Float16)x[2 * i], (_Float16)x[2 * i + 1]};
+        const f16x2 l = {(_Float16)(x[2 * i] - (float)h[0]), (_Float16)(x[2 * i + 1] - (float)h[1])};
+        out[0][i] = __builtin_bit_cast(unsigned, h);
+        out[1][i] = __builtin_bit_cast(unsigned, l);
+    }
+}
+
+#define TMFH(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
 #define TMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
-#define TMF6(A3, B3, C_)       \
-    if (TERMS == 6) {          \
-        TMF(A3[2], B3[0], C_); \
-        TMF(A3[1], B3[1], C_); \
-        TMF(A3[0], B3[2], C_); \
-    }                          \
-    if (TERMS >= 3) {          \
-        TMF(A3[1], B3[0], C_); \
-        TMF(A3[0], B3[1], C_); \
-    }                          \
-    TMF(A3[0], B3[0], C_);
+// all terms of one (channel tile, position tile) product, small terms first: fp16 a2b1 a1b2 a1b1; bf16 a3b1 a2b2 a1b3 a2b1
+// a1b2 a1b1 (six), the last three (KWS_DTYPE_BF16X3) or the last one (KWS_DTYPE_BF16)
+#define TMF6(A3, B3, C_)           \
+    if (F16) {                     \
+        TMFH(A3[1], B3[0], C_);    \
+        TMFH(A3[0], B3[1], C_);    \
+        TMFH(A3[0], B3[0], C_);    \
+    } else {                       \
+        if (TERMS == 6) {          \
+            TMF(A3[2], B3[0], C_); \
+            TMF(A3[1], B3[1], C_); \
+            TMF(A3[0], B3[2], C_); \
+        }                          \
+        if (TERMS >= 3) {          \
+            TMF(A3[1], B3[0], C_); \
+            TMF(A3[0], B3[1], C_); \
+        }                          \
+        TMF(A3[0], B3[0], C_);     \
+    }
 }  // namespace
 
-// NB: 8-channel blocks per cell (3: C <= 24, 6: C <= 48); MT: 16-channel output tiles (2 / 3)
-template <int NB, int MT, int TERMS>
+// NB: 8-channel blocks per cell (3: C <= 24, 6: C <= 48); MT: 16-channel output tiles (2 / 3).
+// F16 (the default, fp32-accurate): operands are two-part fp16 splits, three terms per product (res8_f16x3.hip; weights
+// arrive scaled by 2^S, the accumulator is scaled back in the epilogue's FMA); the LDS cell shrinks to 2 x NB*8 x 2 B, which
+// buys 320-position tiles (5 per wave).  Otherwise bf16 parts with TERMS = 6 / 3 / 1 products (reduced-precision dtypes).
+template <int NB, int MT, int TERMS, bool F16>
 __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) {
-    constexpr int CELL = NB * 48, PART = NB * 16;   // LDS cell: 3 parts x NB*8 channels x 2 B
+    constexpr int LP = F16 ? 2 : 3;                 // parts per LDS cell / per weight fragment group
+    constexpr int CELL = NB * 16 * LP, PART = NB * 16;
     constexpr int GCELL = NB * 32;                  // global cell: NB*8 channels x 4 B
     constexpr int STEPS = (9 * NB + 3) / 4;
-    constexpr int NP = TERMS == 6 ? 3 : (TERMS == 3 ? 2 : 1);   // parts that take part in the products
+    constexpr int NP = F16 ? 2 : (TERMS == 6 ? 3 : (TERMS == 3 ? 2 : 1));   // parts that take part in the products
+    constexpr int TILE_P = F16 ? T3_TILE_P_F16 : T3_TILE_P;
+    constexpr int JT = TILE_P / 64;                 // position tiles per wave (5 / 3)
     constexpr int NQ = NB * 2;         // 4-channel quads per cell
     constexpr int NGRP = 256 / NQ;     // cells copied per pass (21 / 42)
-    constexpr int UNR = NB == 6 ? 14 : 7;  // passes in flight together: a whole tile for W <= 40
+    constexpr int UNR = NB == 6 ? 10 : 5;  // staging passes in flight together
     extern __shared__ __align__(16) char lds[];
 
     const int tid = threadIdx.x;
@@ -123,11 +150,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
     const float inv_ws = 1.0f / (float)Ws, inv_hs = 1.0f / (float)Hs;
 
     // ---------------------------------------------------------------- this lane's three output positions
-    int lbase[3], tmask[3], ob[3], oy[3], ox[3];
-    bool valid[3];
+    int lbase[JT], tmask[JT], ob[JT], oy[JT], ox[JT];
+    bool valid[JT];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int local = (w * 3 + j) * 16 + pcol;
+    for (int j = 0; j < JT; ++j) {
+        const int local = (w * JT + j) * 16 + pcol;
         const int P = P0 + local;
         int xs, ys;
         const int t = fdiv(P, Ws, inv_ws, xs);
@@ -156,11 +183,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
     }
 
     // residual values of this lane's outputs: requested now, consumed in the epilogue
-    f32x4 resv[3][MT];
+    f32x4 resv[JT][MT];
     const char* const resp = reinterpret_cast<const char*>(p.res);
     if (resp) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < JT; ++j) {
             const size_t rcell = (size_t)layout_cell(ob[j], oy[j], ox[j], p.ld_res, p.H, p.W) * GCELL;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -190,10 +217,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
                 for (int u = 0; u < UNR; ++u) {
                     const int i = i0 + u * NGRP;
                     if (i < ncell) {
-                        u32x2 pr[3];
-                        split4(v[u], pr);
+                        if (F16) {
+                            u32x2 pr[2];
+                            split4_f16(v[u], pr);
 #pragma unroll
-                        for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                            for (int pt = 0; pt < 2; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                        } else {
+                            u32x2 pr[3];
+                            split4(v[u], pr);
+#pragma unroll
+                            for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                        }
                     }
                 }
             }
@@ -203,9 +237,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
 
     const u32x4* A = reinterpret_cast<const u32x4*>(p.apk16) + lane;
 
-    f32x4 acc[3][MT];
+    f32x4 acc[JT][MT];
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < JT; ++j)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -229,25 +263,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
 #define TLOADA(AR, S)                                                                                 \
     {                                                                                                 \
         _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                \
-            _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) AR[m][pt] = A[(((S) * MT + m) * 3 + pt) * 64]; \
+            _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) AR[m][pt] = A[(((S) * MT + m) * LP + pt) * 64]; \
     }
-    // one k-step: B fragments are fetched one position tile ahead (tile 0 of the next step during tile 2); BX / BY are
-    // the two fragment buffers, BX holding tile 0 on entry and BY holding the next step's tile 0 on exit
+    // one k-step: B fragments are fetched one position tile ahead (tile 0 of the next step during the last tile); BX / BY
+    // are the two fragment buffers, BX holding tile 0 on entry; JT is odd, so BY holds the next step's tile 0 on exit
 #define TSTEP(AR, BX, BY, OFFN, TAPN)                                                                 \
     {                                                                                                 \
-        TLOADB(BY, b_addr(1, tap_c, off_c))                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], BX, acc[0][m]) }                 \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        TLOADB(BX, b_addr(2, tap_c, off_c))                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], BY, acc[1][m]) }                 \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        TLOADB(BY, b_addr(0, TAPN, OFFN))                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], BX, acc[2][m]) }                 \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
+        _Pragma("unroll") for (int j = 0; j < JT; ++j) {                                              \
+            u32x4 (&cur_)[NP] = (j & 1) ? BY : BX;                                                    \
+            u32x4 (&nxt_)[NP] = (j & 1) ? BX : BY;                                                    \
+            TLOADB(nxt_, j + 1 < JT ? b_addr(j + 1, tap_c, off_c) : b_addr(0, TAPN, OFFN))            \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], cur_, acc[j][m]) }           \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
     }
+    static_assert(JT % 2 == 1, "the fragment buffers swap roles every k-step");
 
     u32x4 a0[MT][NP], a1[MT][NP], bb0[NP], bb1[NP];
     int tap_c, off_c = step_off(0, tap_c);
@@ -275,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
     // ---------------------------------------------------------------- epilogue
     char* const outp = reinterpret_cast<char*>(p.out);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < JT; ++j) {
         if (!valid[j]) continue;
         const int bmask = (oy[j] - d >= 0 ? 1 : 0) | (oy[j] + d < p.H ? 2 : 0) | (ox[j] - d >= 0 ? 4 : 0) |
                           (ox[j] + d < p.W ? 8 : 0);
@@ -288,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
             if (p.border) bb = *reinterpret_cast<const f32x4*>(p.border + bmask * (NB * 8) + co0);   // rows padded to NB*8, zeros past Cout
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = relu1(acc[j][m][r] + bb[r]);
+                float x = relu1(fmaf(acc[j][m][r], p.inv_scale, bb[r]));   // inv_scale = 2^-S of the fp16 weights (1 for bf16)
                 if (resp) x += resv[j][m][r];
                 v[r] = co0 + r < p.Cout ? x : 0.f;   // padded channels hold exact zeros
             }
@@ -297,48 +328,72 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
     }
 }
 
-size_t conv3x3_tile_lds_bytes(int cp, int Ws) { return (size_t)(T3_TILE_P + 2 * Ws + 3) * cp * 6; }
+// one tile buffer (TILE_P + 2 Ws + 2 cells + the zero cell)
+size_t conv3x3_tile_lds_bytes(int cp, int Ws, bool f16) {
+    return (size_t)((f16 ? T3_TILE_P_F16 : T3_TILE_P) + 2 * Ws + 3) * cp * (f16 ? 4 : 6);
+}
 
 bool conv3x3_tile_supported(int C, int Cout, int Ws) {
     const int cp = (C + 7) / 8 * 8;
-    return C == Cout && (cp == 24 || cp == 48) && conv3x3_tile_lds_bytes(cp, Ws) <= 160 * 1024 - 512;
+    return C == Cout && (cp == 24 || cp == 48) && conv3x3_tile_lds_bytes(cp, Ws, false) <= 160 * 1024 - 512 &&
+           conv3x3_tile_lds_bytes(cp, Ws, true) <= 160 * 1024 - 512;
+}
+
+template <int NB, int MT, int TERMS, bool F16>
+static hipError_t launch_t3k(const TileConvParams& p, hipStream_t s) {
+    constexpr int tile = F16 ? T3_TILE_P_F16 : T3_TILE_P;
+    const unsigned grid = (unsigned)((p.total + tile - 1) / tile);
+    const size_t lds = conv3x3_tile_lds_bytes(NB * 8, p.Ws, F16);
+    auto k = conv3x3_tile_kernel<NB, MT, TERMS, F16>;
+    static bool attr_done = false;   // per instantiation: allow > 64 KB of dynamic LDS
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+    return hipGetLastError();
 }
 
 template <int NB, int MT>
 static hipError_t launch_t3(const TileConvParams& p, hipStream_t s) {
-    const unsigned grid = (unsigned)((p.total + T3_TILE_P - 1) / T3_TILE_P);
-    const size_t lds = conv3x3_tile_lds_bytes(NB * 8, p.Ws);
-    auto k6 = conv3x3_tile_kernel<NB, MT, 6>;
-    auto k3 = conv3x3_tile_kernel<NB, MT, 3>;
-    auto k1 = conv3x3_tile_kernel<NB, MT, 1>;
-    static bool attr_done = false;   // per instantiation: allow > 64 KB of dynamic LDS
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    if (p.terms == 1)
-        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, s, p);
-    else if (p.terms == 3)
-        hipLaunchKernelGGL(k3, dim3(grid), dim3(256), lds, s, p);
-    else
-        hipLaunchKernelGGL(k6, dim3(grid), dim3(256), lds, s, p);
-    return hipGetLastError();
+    if (p.f16) return launch_t3k<NB, MT, 3, true>(p, s);
+    if (p.terms == 1) return launch_t3k<NB, MT, 1, false>(p, s);
+    if (p.terms == 3) return launch_t3k<NB, MT, 3, false>(p, s);
+    return launch_t3k<NB, MT, 6, false>(p, s);
 }
 
 hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s) {
     if (p.total <= 0) return hipSuccess;
     const int cp = (C + 7) / 8 * 8;
     // positions are decoded with fp32 reciprocals (exact below 2^24) and byte offsets are 32-bit
-    if (!conv3x3_tile_supported(C, p.Cout, p.Ws) || (long long)p.total + T3_TILE_P + 2 * p.Ws + 2 >= (1 << 24) ||
+    if (!conv3x3_tile_supported(C, p.Cout, p.Ws) || (long long)p.total + T3_TILE_P_F16 + 2 * p.Ws + 2 >= (1 << 24) ||
         (long long)p.total * cp * 4 >= (1LL << 31))
         return hipErrorInvalidValue;
     if (cp == 48) return launch_t3<6, 3>(p, s);
     return launch_t3<3, 2>(p, s);
+}
+
+// Weights (Cout, Cin, 3, 3) times `scale` -> two fp16 parts in the fragment order of pack_conv_weights_bf16x6 with all channel
+// tiles in one group: [k-step][channel tile][part 2][lane][8]; block bi = 4 s + (lane >> 4) = (tap, 8-channel block)
+void pack_conv3x3_tile_weights_f16(int C, const float* w, float scale, std::vector<unsigned short>& dst) {
+    const int nb = (C + 7) / 8, mt = (C + 15) / 16, steps = (9 * nb + 3) / 4;
+    dst.assign((size_t)steps * mt * 2 * 64 * 8, 0);
+    for (int s = 0; s < steps; ++s)
+        for (int m = 0; m < mt; ++m)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = m * 16 + (lane & 15), bi = 4 * s + (lane >> 4);
+                const int tap = bi / nb, cb = bi % nb;
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = 8 * cb + e;
+                    float v = 0.f;
+                    if (bi < 9 * nb && co < C && ci < C) v = w[((size_t)co * C + ci) * 9 + tap] * scale;
+                    const unsigned short h = f16_rne_host(v);
+                    const unsigned short l = f16_rne_host(v - f16_to_f_host(h));
+                    dst[((((size_t)s * mt + m) * 2 + 0) * 64 + lane) * 8 + e] = h;
+                    dst[((((size_t)s * mt + m) * 2 + 1) * 64 + lane) * 8 + e] = l;
+                }
+            }
 }
 
 // ------------------------------------------------------------------------------------------------ fp32 NCHW -> CL

@@ -59,7 +59,8 @@ enum LwMode { LW_FP32 = 0, LW_NCHW = 1, LW_TILED = 2 };
 
 struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the layer-wise plans
     ConvGeom g{};           // B/H/W/Ho/Wo filled per call for ResNet, at create for CNN
-    DevMem apk, apk16, bias, border, border_pad;   // border_pad: rows padded to a multiple of 8 channels (tiled kernel)
+    DevMem apk, apk16, apk_t3h, bias, border, border_pad;   // apk_t3h: fp16 fragments of the tiled 3x3 kernel
+    float t3h_scale = 1.f;   // 2^S of apk_t3h   // border_pad: rows padded to a multiple of 8 channels (tiled kernel)
     bool has_bias = false, has_border = false, use_x = false;   // use_x: bf16x6 kernel available for this layer
     std::vector<float> w_host;   // ResNet: raw weights kept until finalize() folds the previous BatchNorm in
 };
@@ -376,6 +377,12 @@ int finalize(kws_handle* h) {
                 L.has_border = true;
             }
             if ((rc = upload_packed(L, wf.data(), h->lw_mode))) return rc;
+            if (i >= 1 && h->lw_mode == LW_TILED && conv3x3_tile_supported(C, C, 1)) {
+                std::vector<unsigned short> pk;
+                L.t3h_scale = weight_scale_pow2(wf.data(), wf.size());
+                pack_conv3x3_tile_weights_f16(C, wf.data(), L.t3h_scale, pk);
+                if ((rc = L.apk_t3h.upload(pk.data(), pk.size() * sizeof(unsigned short)))) return rc;
+            }
         }
         if (h->res8_eligible) {
             std::vector<float> tab((size_t)R8_LAYERS * 96, 0.f);
@@ -544,7 +551,9 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
             tp.in = even ? Y : xc;
             tp.out = even ? xn : Y;
             tp.res = even ? xc : nullptr;
-            tp.apk16 = h->rconv[i].apk16.as<unsigned short>();
+            tp.f16 = d.dtype == KWS_DTYPE_F32 ? 1 : 0;   // the reduced-precision dtypes keep bf16 parts
+            tp.apk16 = tp.f16 ? h->rconv[i].apk_t3h.as<unsigned short>() : h->rconv[i].apk16.as<unsigned short>();
+            tp.inv_scale = tp.f16 ? 1.0f / h->rconv[i].t3h_scale : 1.0f;
             tp.border = h->rconv[i].has_border ? h->rconv[i].border_pad.as<float>() : nullptr;
             tp.B = nb; tp.H = sh.H; tp.W = sh.W; tp.Cout = C;
             tp.ld_in = ld_in; tp.ld_out = ld_out; tp.ld_res = ld_x;
@@ -812,7 +821,7 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
                 } else {
                     pack_res8_layer(src, h->r8_apk_host.data() + (size_t)(idx - 1) * R8_GROUPS * 3 * 64 * 4);
                     pack_res8x_layer(src, h->r8x_apk_host.data() + (size_t)(idx - 1) * R8X_KSTEPS * 3 * 3 * 64 * 8);
-                    h->r8h_scale[idx - 1] = res8h_weight_scale(src, n);
+                    h->r8h_scale[idx - 1] = weight_scale_pow2(src, n);
                     pack_res8h_layer(src, h->r8h_scale[idx - 1],
                                      h->r8h_apk_host.data() + (size_t)(idx - 1) * R8X_KSTEPS * 3 * 2 * 64 * 8);
                 }

@@ -2,13 +2,61 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/kws.h"
 
 namespace kws {
+
+// ---------------------------------------------------------------- host-side fp16 helpers (weight packing of the fp16 paths)
+// fp32 -> fp16 bits, round to nearest even; subnormals and overflow handled (weights are finite)
+inline unsigned short f16_rne_host(float x) {
+    unsigned u;
+    std::memcpy(&u, &x, 4);
+    const unsigned sign = (u >> 16) & 0x8000u;
+    const int e = (int)((u >> 23) & 0xffu) - 127 + 15;
+    unsigned m = u & 0x7fffffu;
+    if (((u >> 23) & 0xffu) == 0) return (unsigned short)sign;            // fp32 zero / subnormal -> 0
+    if (e >= 31) return (unsigned short)(sign | 0x7c00u);                  // overflow -> inf
+    if (e <= 0) {                                                          // fp16 subnormal (or underflow to 0)
+        if (e < -10) return (unsigned short)sign;
+        m |= 0x800000u;
+        const int shift = 14 - e;
+        const unsigned q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        return (unsigned short)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+    }
+    const unsigned q = m >> 13, rem = m & 0x1fffu;
+    unsigned r = ((unsigned)e << 10) | q;
+    if (rem > 0x1000u || (rem == 0x1000u && (q & 1u))) ++r;               // a carry into the exponent is the right result
+    return (unsigned short)(sign | r);
+}
+inline float f16_to_f_host(unsigned short h) {
+    const unsigned sign = (unsigned)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 0x1f;
+    const unsigned m = h & 0x3ffu;
+    float f;
+    if (e == 0) {
+        f = std::ldexp((float)m, -24);
+        return sign ? -f : f;
+    }
+    const unsigned u = sign | ((unsigned)(e - 15 + 127) << 23) | (m << 13);
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// power-of-two scale that brings the largest |weight| of a layer into [128, 256): the second fp16 part of every weight
+// then stays in (or near) the normal range
+inline float weight_scale_pow2(const float* w, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(w[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.f;
+    int ex;
+    std::frexp(mx, &ex);                 // mx = f * 2^ex, f in [0.5, 1)
+    return std::ldexp(1.f, 8 - ex);
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -121,7 +169,6 @@ struct Res8hParams {
 };
 size_t res8h_lds_bytes();
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s);
-float res8h_weight_scale(const float* w /*45x45x3x3*/, size_t n);
 void pack_res8h_layer(const float* w /*45x45x3x3*/, float scale, unsigned short* dst /*R8X_KSTEPS*3*2*64*8*/);
 
 // ---------------------------------------------------------------- layer-wise kernels (layerwise.hip)
@@ -165,20 +212,24 @@ hipError_t launch_conv_bf16x6(const ConvGeom& g, const ConvArgs& a, hipStream_t 
 void pack_conv_weights_bf16x6(const ConvGeom& g, const float* w, std::vector<unsigned short>& dst);
 // LDS-tiled 3x3 "same" conv with power-of-two dilation over channels-last fp32 tensors in sub-map layouts
 // (conv3x3_tile.hip)
-constexpr int T3_TILE_P = 192;
+constexpr int T3_TILE_P = 192;         // bf16 parts (reduced-precision dtypes): 3 position tiles per wave
+constexpr int T3_TILE_P_F16 = 320;     // fp16 parts (default): 5 position tiles per wave
 struct TileConvParams {
     const float* in;       // CL tensor in layout(2^ld_in): [clip][y mod d][x mod d][ceil(H/d)][ceil(W/d)][cp] fp32
     float* out;            // CL tensor, written in layout(2^ld_out)
     const float* res;      // residual CL tensor in layout(2^ld_res), or nullptr
-    const unsigned short* apk16;   // pack_conv_weights_bf16x6 with MT = all channel tiles
+    const unsigned short* apk16;   // f16: pack_conv3x3_tile_weights_f16; else pack_conv_weights_bf16x6 with MT = all tiles
     const float* border;   // (16, C padded to 8) border-bias table, zeros in the padding, or nullptr
     int B, H, W, Cout;
     int ld_in, ld_out, ld_res;
     int Hs, Ws;            // ceil(H / d_in), ceil(W / d_in)
     int total;             // B * d_in^2 * Hs * Ws cells of the input layout
-    int terms;
+    int terms;             // bf16 parts only: 6 / 3 / 1 terms per product
+    int f16;               // 1: two-part fp16 operands, three terms (fp32-accurate default)
+    float inv_scale;       // 2^-S of the fp16 weights (1 for bf16)
 };
 bool conv3x3_tile_supported(int C, int Cout, int Ws);
+void pack_conv3x3_tile_weights_f16(int C, const float* w /*C,C,3,3*/, float scale, std::vector<unsigned short>& dst);
 hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
 // fp32 (B, C, H, W) -> pooled (stride = window, floor; 1 x 1 = transpose only) channels-last (B, H/kh, W/kw, cp) fp32
 hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, int W, int kh, int kw, int is_max, int cp,

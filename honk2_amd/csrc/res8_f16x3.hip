@@ -425,55 +425,6 @@ hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------- host packing
-namespace {
-// fp32 -> fp16 bits, round to nearest even, subnormals and overflow handled (no NaN inputs here)
-unsigned short f16_rne(float x) {
-    unsigned u;
-    std::memcpy(&u, &x, 4);
-    const unsigned sign = (u >> 16) & 0x8000u;
-    const int e = (int)((u >> 23) & 0xffu) - 127 + 15;
-    unsigned m = u & 0x7fffffu;
-    if (((u >> 23) & 0xffu) == 0) return (unsigned short)sign;            // fp32 zero / subnormal -> 0
-    if (e >= 31) return (unsigned short)(sign | 0x7c00u);                  // overflow -> inf
-    if (e <= 0) {                                                          // fp16 subnormal (or underflow to 0)
-        if (e < -10) return (unsigned short)sign;
-        m |= 0x800000u;
-        const int shift = 14 - e;                                          // 24-bit significand -> 10 - (1 - e) bits
-        const unsigned q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
-        const unsigned r = q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u);
-        return (unsigned short)(sign | r);
-    }
-    const unsigned q = m >> 13, rem = m & 0x1fffu;
-    unsigned r = ((unsigned)e << 10) | q;
-    if (rem > 0x1000u || (rem == 0x1000u && (q & 1u))) ++r;               // a carry into the exponent is the right result
-    return (unsigned short)(sign | r);
-}
-float f16_to_f(unsigned short h) {
-    const unsigned sign = (unsigned)(h & 0x8000u) << 16;
-    const int e = (h >> 10) & 0x1f;
-    const unsigned m = h & 0x3ffu;
-    float f;
-    if (e == 0) {
-        f = std::ldexp((float)m, -24);
-        if (sign) f = -f;
-        return f;
-    }
-    const unsigned u = sign | ((unsigned)(e - 15 + 127) << 23) | (m << 13);
-    std::memcpy(&f, &u, 4);
-    return f;
-}
-}  // namespace
-
-// power-of-two scale that brings the layer's largest |weight| into [128, 256)
-float res8h_weight_scale(const float* wt, size_t n) {
-    float mx = 0.f;
-    for (size_t i = 0; i < n; ++i) mx = std::fmax(mx, std::fabs(wt[i]));
-    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.f;
-    int ex;
-    std::frexp(mx, &ex);                 // mx = f * 2^ex, f in [0.5, 1)
-    return std::ldexp(1.f, 8 - ex);      // mx * scale in [128, 256)
-}
-
 // conv_i weight (45,45,3,3) times `scale` -> [k-step 14][channel tile 3][part 2][lane 64][8 fp16]:
 //   cout = 16 m + (lane & 15); block bi = 4 s + (lane >> 4): tap = bi / 6, input channels 8 (bi % 6) .. +7; bi >= 54: zeros
 void pack_res8h_layer(const float* wt, float scale, unsigned short* dst) {
@@ -487,8 +438,8 @@ void pack_res8h_layer(const float* wt, float scale, unsigned short* dst) {
                         const int tap = bi / 6, ci = 8 * (bi % 6) + j;
                         if (ci < R8_C) v = wt[((size_t)co * R8_C + ci) * 9 + tap] * scale;
                     }
-                    const unsigned short h = f16_rne(v);
-                    const unsigned short l = f16_rne(v - f16_to_f(h));
+                    const unsigned short h = f16_rne_host(v);
+                    const unsigned short l = f16_rne_host(v - f16_to_f_host(h));
                     dst[((((size_t)s * 3 + m) * 2 + 0) * 64 + lane) * 8 + j] = h;
                     dst[((((size_t)s * 3 + m) * 2 + 1) * 64 + lane) * 8 + j] = l;
                 }
