@@ -59,7 +59,8 @@ enum LwMode { LW_FP32 = 0, LW_NCHW = 1, LW_TILED = 2 };
 
 struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the layer-wise plans
     ConvGeom g{};           // B/H/W/Ho/Wo filled per call for ResNet, at create for CNN
-    DevMem apk, apk16, apk_t3h, bias, border, border_pad;   // apk_t3h: fp16 fragments of the tiled 3x3 kernel
+    DevMem apk, apk16, apk16h, apk_t3h, bias, border, border_pad;   // apk16h: fp16 fragments of the generic kernel
+    float x_scale = 1.f;     // 2^S of apk16h   // apk_t3h: fp16 fragments of the tiled 3x3 kernel
     float t3h_scale = 1.f;   // 2^S of apk_t3h   // border_pad: rows padded to a multiple of 8 channels (tiled kernel)
     bool has_bias = false, has_border = false, use_x = false;   // use_x: bf16x6 kernel available for this layer
     std::vector<float> w_host;   // ResNet: raw weights kept until finalize() folds the previous BatchNorm in
@@ -301,7 +302,10 @@ int upload_packed(ConvLayer& L, const float* w, LwMode mode) {
     if (L.use_x) {
         std::vector<unsigned short> pk16;
         pack_conv_weights_bf16x6(L.g, w, pk16);
-        rc = L.apk16.upload(pk16.data(), pk16.size() * sizeof(unsigned short));
+        if ((rc = L.apk16.upload(pk16.data(), pk16.size() * sizeof(unsigned short)))) return rc;
+        L.x_scale = weight_scale_pow2(w, (size_t)L.g.Cout * L.g.Cin * L.g.kh * L.g.kw);
+        pack_conv_weights_f16x3(L.g, w, L.x_scale, pk16);
+        rc = L.apk16h.upload(pk16.data(), pk16.size() * sizeof(unsigned short));
     }
     return rc;
 }
@@ -310,8 +314,10 @@ int upload_packed(ConvLayer& L, const float* w, LwMode mode) {
 int launch_layer(const ConvLayer& L, const ConvGeom& g_in, ConvArgs a, hipStream_t s, int terms = 6) {
     ConvGeom g = g_in;
     g.x_terms = terms;
+    g.x_f16 = terms == 6 ? 1 : 0;   // the fp32-accurate default runs on fp16 parts; bf16x3 / bf16 dtypes on bf16 parts
+    g.x_inv_scale = g.x_f16 ? 1.0f / L.x_scale : 1.0f;
     if (L.use_x) {
-        a.apk16 = L.apk16.as<unsigned short>();
+        a.apk16 = g.x_f16 ? L.apk16h.as<unsigned short>() : L.apk16.as<unsigned short>();
         HIP_TRY(launch_conv_bf16x6(g, a, s));
     } else {
         HIP_TRY(launch_conv(g, a, s));

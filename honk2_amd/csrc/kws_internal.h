@@ -188,7 +188,9 @@ struct ConvGeom {
     int x_ksteps;          // ceil(x_blocks / 4): k-steps of v_mfma_f32_16x16x32_bf16
     int x_mt;              // bf16 kernel: channel tiles per wave (conv_bf16x6_geometry)
     int x_mt_cap;          // > 0: upper bound for x_mt (3 for convs whose pooling window needs several passes)
-    int x_terms;           // bf16 kernel: 6 (fp32-accurate), 3 (KWS_DTYPE_BF16X3) or 1 (KWS_DTYPE_BF16)
+    int x_terms;           // bf16 parts: 6 (fp32-accurate), 3 (KWS_DTYPE_BF16X3) or 1 (KWS_DTYPE_BF16) terms per product
+    int x_f16;             // 1: two-part fp16 operands, three terms (the fp32-accurate default); weights carry 2^S
+    float x_inv_scale;     // 2^-S (1 when not x_f16), applied to the accumulator in the epilogue
     int pool_h, pool_w;    // conv_bf16x6_kernel only: fused MaxPool window (stride = window, floor), <= 16 members; 0 / 1 = none
     int ksplit;            // > 1: K range split over blockIdx.z (flat Cin == 1 mode only); partial sums go to ConvArgs::partial
     int ksteps_split;      // k-steps per split
@@ -210,6 +212,7 @@ bool conv_bf16x6_supported(const ConvGeom& g);
 void conv_bf16x6_geometry(ConvGeom& g);
 hipError_t launch_conv_bf16x6(const ConvGeom& g, const ConvArgs& a, hipStream_t s);
 void pack_conv_weights_bf16x6(const ConvGeom& g, const float* w, std::vector<unsigned short>& dst);
+void pack_conv_weights_f16x3(const ConvGeom& g, const float* w, float scale, std::vector<unsigned short>& dst);
 // LDS-tiled 3x3 "same" conv with power-of-two dilation over channels-last fp32 tensors in sub-map layouts
 // (conv3x3_tile.hip)
 constexpr int T3_TILE_P = 192;         // bf16 parts (reduced-precision dtypes): 3 position tiles per wave

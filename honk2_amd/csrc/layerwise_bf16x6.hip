@@ -24,6 +24,8 @@ namespace kws {
 namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int OOB = (int)0x80000000;
@@ -56,23 +58,44 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[3]) {
     }
 }
 
+// 8 fp32 values -> two fp16x8 fragments (x = h + l to 22 bits; exact products in three terms, see res8_f16x3.hip)
+__device__ __forceinline__ void split8_f16(const float (&x)[8], u32x4 (&out)[3]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x2 h = {(_Float16)x[2 * i], (_Float16)x[2 * i + 1]};
+        const f16x2 l = {(_Float16)(x[2 * i] - (float)h[0]), (_Float16)(x[2 * i + 1] - (float)h[1])};
+        out[0][i] = __builtin_bit_cast(unsigned, h);
+        out[1][i] = __builtin_bit_cast(unsigned, l);
+    }
+}
+
+#define XMFH(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
 #define XMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
-#define XMF6(A3, B3, C_)       \
-    if (TERMS == 6) {          \
-        XMF(A3[2], B3[0], C_); \
-        XMF(A3[1], B3[1], C_); \
-        XMF(A3[0], B3[2], C_); \
-    }                          \
-    if (TERMS >= 3) {          \
-        XMF(A3[1], B3[0], C_); \
-        XMF(A3[0], B3[1], C_); \
-    }                          \
-    XMF(A3[0], B3[0], C_);
+#define XMF6(A3, B3, C_)            \
+    if (F16) {                      \
+        XMFH(A3[1], B3[0], C_);     \
+        XMFH(A3[0], B3[1], C_);     \
+        XMFH(A3[0], B3[0], C_);     \
+    } else {                        \
+        if (TERMS == 6) {           \
+            XMF(A3[2], B3[0], C_);  \
+            XMF(A3[1], B3[1], C_);  \
+            XMF(A3[0], B3[2], C_);  \
+        }                           \
+        if (TERMS >= 3) {           \
+            XMF(A3[1], B3[0], C_);  \
+            XMF(A3[0], B3[1], C_);  \
+        }                           \
+        XMF(A3[0], B3[0], C_);      \
+    }
 }  // namespace
 
 // MULTI: pooling windows of more than four members (several passes over K with a running maximum)
-template <int MT, bool KX, int TERMS, bool MULTI>
+// F16 (the fp32-accurate default): two-part fp16 operands, three terms, weights scaled by 2^S (gm.x_inv_scale = 2^-S is applied
+// in the epilogue); otherwise bf16 parts with TERMS = 6 / 3 / 1 products.
+template <int MT, bool KX, int TERMS, bool MULTI, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvArgs a) {
+    constexpr int LP = F16 ? 2 : 3;   // weight parts per fragment group
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
     const int s_begin = gm.ksplit > 1 ? (int)blockIdx.z * gm.ksteps_split : 0;
     const int s_end = gm.ksplit > 1 ? min(steps, s_begin + gm.ksteps_split) : steps;
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(a.apk16 + (size_t)blockIdx.y * steps * MT * 3 * 64 * 8), 0, steps * MT * 3 * 1024,
+        const_cast<unsigned short*>(a.apk16 + (size_t)blockIdx.y * steps * MT * LP * 64 * 8), 0, steps * MT * LP * 1024,
         0x00020000);
 
     // inner/outer split of the block index: blocks per "row" (tap for Cin > 1, kernel row for Cin == 1)
@@ -176,12 +199,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
     {                                                                                                 \
         u32x4 wa_[MT][3];                                                                             \
         _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                \
-            _Pragma("unroll") for (int pt = 0; pt < 3; ++pt)                                          \
-                wa_[m][pt] = bload4(rwt, lane * 16 + (m * 3 + pt) * 1024, (S) * MT * 3 * 1024);       \
+            _Pragma("unroll") for (int pt = 0; pt < LP; ++pt)                                         \
+                wa_[m][pt] = bload4(rwt, lane * 16 + (m * LP + pt) * 1024, (S) * MT * LP * 1024);     \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
             if (j >= ntile) continue;          /* windows with fewer members than tiles (uniform branch) */ \
             u32x4 bs_[3];                                                                             \
-            split8(RAW[j], bs_);                                                                      \
+            if (F16) split8_f16(RAW[j], bs_); else split8(RAW[j], bs_);                               \
             _Pragma("unroll") for (int m = 0; m < MT; ++m) { XMF6(wa_[m], bs_, acc[m][j]) }           \
         }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
                     for (int j = 1; j < 4; ++j)
                         if (j < nmem) v = fmaxf(v, acc[m][j][r]);
                 }
-                v += bias;
+                v = fmaf(v, gm.x_inv_scale, bias);   // 2^-S > 0 commutes with the maximum
                 if (gm.relu) v = fmaxf(v, 0.f);
                 a.out[((size_t)bidx[0] * gm.Cout + co) * npc + pos[0]] = v;
                 continue;
@@ -261,10 +284,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
             for (int j = 0; j < 4; ++j) {
                 if (!valid[j]) continue;
                 if (gm.ksplit > 1) {
-                    a.partial[((size_t)blockIdx.z * gm.B + bidx[j]) * gm.Cout * npc + (size_t)co * npc + pos[j]] = acc[m][j][r];
+                    a.partial[((size_t)blockIdx.z * gm.B + bidx[j]) * gm.Cout * npc + (size_t)co * npc + pos[j]] =
+                        acc[m][j][r] * gm.x_inv_scale;
                     continue;
                 }
-                float v = acc[m][j][r] + bias;
+                float v = fmaf(acc[m][j][r], gm.x_inv_scale, bias);
                 if (a.border) v += a.border[bmask[j] * gm.Cout + co];
                 if (gm.relu) v = fmaxf(v, 0.f);
                 const size_t idx = ((size_t)bidx[j] * gm.Cout + co) * npc + pos[j];
@@ -281,23 +305,25 @@ static hipError_t launch_x_mt(const ConvGeom& g, const ConvArgs& a, hipStream_t 
     const int per_wg = pooled ? 64 : 256;
     dim3 grid((unsigned)((ntot + per_wg - 1) / per_wg), (unsigned)((g.mtiles + MT - 1) / MT), (unsigned)(g.ksplit > 1 ? g.ksplit : 1));
     const bool multi = pooled && g.pool_h * g.pool_w > 4;
-#define X_LAUNCH(KX_, T_, M_) hipLaunchKernelGGL((conv_bf16x6_kernel<MT, KX_, T_, M_>), grid, dim3(256), 0, s, g, a)
-#define X_LAUNCH_T(T_)                                  \
-    if (multi) {                                        \
-        if (MT > 3) return hipErrorInvalidValue;        \
-        if (g.kx_inner) X_LAUNCH(true, T_, (MT <= 3));  \
-        else X_LAUNCH(false, T_, (MT <= 3));            \
-    } else {                                            \
-        if (g.kx_inner) X_LAUNCH(true, T_, false);      \
-        else X_LAUNCH(false, T_, false);                \
-    }
-    if (g.x_terms == 1) {
-        X_LAUNCH_T(1)
-    } else if (g.x_terms == 3) {
-        X_LAUNCH_T(3)
-    } else {
-        X_LAUNCH_T(6)
-    }
+#define X_LAUNCH(KX_, T_, M_)                                                                                      \
+    do {                                                                                                           \
+        if (g.x_f16) hipLaunchKernelGGL((conv_bf16x6_kernel<MT, KX_, 3, M_, true>), grid, dim3(256), 0, s, g, a);  \
+        else hipLaunchKernelGGL((conv_bf16x6_kernel<MT, KX_, T_, M_, false>), grid, dim3(256), 0, s, g, a);        \
+    } while (0)
+#define X_LAUNCH_T(T_)                                         \
+    do {                                                       \
+        if (multi) {                                           \
+            if (MT > 3) return hipErrorInvalidValue;           \
+            if (g.kx_inner) X_LAUNCH(true, T_, (MT <= 3));     \
+            else X_LAUNCH(false, T_, (MT <= 3));               \
+        } else {                                               \
+            if (g.kx_inner) X_LAUNCH(true, T_, false);         \
+            else X_LAUNCH(false, T_, false);                   \
+        }                                                      \
+    } while (0)
+    if (g.x_terms == 1) X_LAUNCH_T(1);
+    else if (g.x_terms == 3) X_LAUNCH_T(3);
+    else X_LAUNCH_T(6);
 #undef X_LAUNCH_T
 #undef X_LAUNCH
     return hipGetLastError();
@@ -362,6 +388,37 @@ void conv_bf16x6_geometry(ConvGeom& g) {
         }
     }
     g.x_mt = best;
+}
+
+// fp16 variant: weights times `scale` -> [mgroup][k-step][MT][part 2][lane][8 fp16], same block order
+void pack_conv_weights_f16x3(const ConvGeom& g, const float* w, float scale, std::vector<unsigned short>& dst) {
+    const int mgroups = (g.mtiles + g.x_mt - 1) / g.x_mt;
+    dst.assign((size_t)mgroups * g.x_ksteps * g.x_mt * 2 * 64 * 8, 0);
+    for (int mg = 0; mg < mgroups; ++mg)
+        for (int s = 0; s < g.x_ksteps; ++s)
+            for (int m = 0; m < g.x_mt; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = (mg * g.x_mt + m) * 16 + (lane & 15);
+                    const int bi = 4 * s + (lane >> 4);
+                    const int r = bi / g.x_blocks_per_row, cb = bi % g.x_blocks_per_row;
+                    for (int e = 0; e < 8; ++e) {
+                        float v = 0.f;
+                        if (bi < g.x_blocks && co < g.Cout) {
+                            if (g.kx_inner) {
+                                const int ky = r, kx = 8 * cb + e;
+                                if (kx < g.kw) v = w[((size_t)co * g.kh + ky) * g.kw + kx];
+                            } else {
+                                const int ky = r / g.kw, kx = r % g.kw, ci = 8 * cb + e;
+                                if (ci < g.Cin) v = w[(((size_t)co * g.Cin + ci) * g.kh + ky) * g.kw + kx];
+                            }
+                        }
+                        v *= scale;
+                        const unsigned short h = f16_rne_host(v);
+                        const unsigned short l = f16_rne_host(v - f16_to_f_host(h));
+                        dst[(((((size_t)mg * g.x_ksteps + s) * g.x_mt + m) * 2 + 0) * 64 + lane) * 8 + e] = h;
+                        dst[(((((size_t)mg * g.x_ksteps + s) * g.x_mt + m) * 2 + 1) * 64 + lane) * 8 + e] = l;
+                    }
+                }
 }
 
 // weights (Cout, Cin, kh, kw) -> [mgroup][k-step][MT][part][lane][8 bf16]; lane = (block slot g << 4) | row
