@@ -94,7 +94,8 @@ struct kws_handle {
     DevMem bn_mean, bn_rstd;               // (n_layers, C) each: the LAST layer's BN is applied after the spatial mean
     DevMem out_w, out_b;
     // fused res8
-    DevMem r8_w0a, r8_apk, r8_bn, r8_zcells, r8x_apk, r8h_apk, r8h_bn;
+    DevMem r8_w0a, r8_apk, r8_bn, r8_zcells, r8x_apk, r8h_apk, r8h_bn, r8h_w0;
+    float r8h_scale0 = 1.f;   // 2^S of conv_0's fp16 weights
     std::vector<float> r8_apk_host;
     std::vector<unsigned short> r8x_apk_host, r8h_apk_host;
     float r8h_scale[R8_LAYERS] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // 2^S per layer (fp16 path)
@@ -701,7 +702,7 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
             if (h->res8_impl == 0) {
                 h->last_plan = "res8_fused";
                 Res8hParams p{};
-                p.feat = feat; p.logits = logits; p.w0a = h->r8_w0a.as<float>(); p.apk2 = h->r8h_apk.p;
+                p.feat = feat; p.logits = logits; p.w0h = h->r8h_w0.p; p.inv_scale0 = 1.0f / h->r8h_scale0; p.apk2 = h->r8h_apk.p;
                 p.bn_tab = h->r8h_bn.as<float>(); p.out_w = h->out_w.as<float>(); p.out_b = h->out_b.as<float>();
                 for (int i = 0; i < R8_LAYERS; ++i) p.inv_scale[i] = 1.0f / h->r8h_scale[i];
                 p.B = B; p.T = T; p.F = h->d.freq; p.n_labels = h->d.n_labels; p.debug = dbg;
@@ -824,6 +825,10 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
                     std::vector<float> frag(3 * 3 * 64);
                     pack_res8_conv0(src, frag.data());
                     if ((rc = h->r8_w0a.upload(frag.data(), frag.size() * 4))) return rc;
+                    std::vector<unsigned short> w0h((size_t)3 * 2 * 64 * 8);
+                    h->r8h_scale0 = weight_scale_pow2(src, n);
+                    pack_res8h_conv0(src, h->r8h_scale0, w0h.data());
+                    if ((rc = h->r8h_w0.upload(w0h.data(), w0h.size() * 2))) return rc;
                 } else {
                     pack_res8_layer(src, h->r8_apk_host.data() + (size_t)(idx - 1) * R8_GROUPS * 3 * 64 * 4);
                     pack_res8x_layer(src, h->r8x_apk_host.data() + (size_t)(idx - 1) * R8X_KSTEPS * 3 * 3 * 64 * 8);

@@ -158,7 +158,8 @@ constexpr size_t R8H_APK_SHORTS = (size_t)R8_LAYERS * R8X_KSTEPS * 3 * 2 * 64 * 
 struct Res8hParams {
     const float* feat;    // (B, 101, 40)
     float* logits;        // (B, n_labels)
-    const float* w0a;     // conv_0 weight as fp32 A fragments (pack_res8_conv0)
+    const void* w0h;      // conv_0 weight * 2^S0 as two fp16 parts, one 16x16x32 A fragment per channel tile (pack_res8h_conv0)
+    float inv_scale0;     // 2^-S0
     const void* apk2;     // conv_1..6 weights * 2^S split into two fp16 parts, fragment order (pack_res8h_layer)
     const float* bn_tab;  // (6, 96): per layer scale[48], shift[48]; the scale of ODD layers carries the layer's 2^-S
     const float* out_w;   // (n_labels, 45)
@@ -170,6 +171,7 @@ struct Res8hParams {
 size_t res8h_lds_bytes();
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s);
 void pack_res8h_layer(const float* w /*45x45x3x3*/, float scale, unsigned short* dst /*R8X_KSTEPS*3*2*64*8*/);
+void pack_res8h_conv0(const float* w /*45x9*/, float scale, unsigned short* dst /*3*2*64*8*/);
 
 // ---------------------------------------------------------------- layer-wise kernels (layerwise.hip)
 struct ConvGeom {

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     XCtx c;
     c.lds = ldsb;
-    float* feat_s = reinterpret_cast<float*>(ldsb);   // conv_0's input is staged where the activation map will be
+    unsigned* feat_w = reinterpret_cast<unsigned*>(ldsb);   // conv_0's input is staged where the activation map will be
     c.red = reinterpret_cast<float*>(ldsb + RED_OFF);
     c.mvec = c.red + 4 * 48;
     float* bnt = c.mvec + 48;
@@ -302,23 +302,28 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                 if (q4 < 1010) {
                     const int idx = 4 * q4;
                     const int cell = idx + idx / 40 + FS + 1;
-                    feat_s[cell] = v[it][0];
-                    feat_s[cell + 1] = v[it][1];
-                    feat_s[cell + 2] = v[it][2];
-                    feat_s[cell + 3] = v[it][3];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {   // one word per feature: fp16 part 1 in the low half, part 2 in the high half
+                        const _Float16 hp = (_Float16)v[it][e];
+                        const f16x2 hl = {hp, (_Float16)(v[it][e] - (float)hp)};
+                        feat_w[cell + e] = __builtin_bit_cast(unsigned, hl);
+                    }
                 }
             }
-            if (tid < FS) feat_s[tid] = 0.f;
-            if (tid < 101) feat_s[(tid + 1) * FS] = 0.f;
+            if (tid < FS) feat_w[tid] = 0u;
+            if (tid < 101) feat_w[(tid + 1) * FS] = 0u;
         }
         __syncthreads();
 
-        // ---- conv_0 + ReLU + AvgPool(4,3): fp32-input MFMA (K = 9), result in accumulator layout = prev_x
+        // ---- conv_0 + ReLU + AvgPool(4,3) on the fp16 matrix cores, result in accumulator layout = prev_x.
+        //      K = 9 taps sit in k-slots 0..8 of one 16x16x32 step: lane group 0 supplies taps 0..7, group 1 tap 8, the rest
+        //      zeros.  Every lane reads eight staged words at compile-time offsets from its window base (group 1's base is
+        //      shifted onto tap 8) and v_perm_b32 gathers the fp16 halves into the two B fragments; per-lane selectors blank
+        //      the k-slots a lane group does not own.  Three terms as in the layers; 2^-S and the 1/12 of the pool ride on
+        //      one multiply.
         f32x4 prev[5][3], prevx;
         {
-            // staged-feature offsets of this lane's pooling windows and taps (conv_0 only: recomputed per clip so that they
-            // do not occupy registers during the layers)
-            int lb[6], koff[3];
+            int lbw[6];   // byte address of the window base of this lane's position in each tile (+ tap 8 for lane group 1)
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int nt = j < 5 ? 5 * w + j : 20;
@@ -326,69 +331,81 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                 const int nn = n < R8_NPOS ? n : R8_NPOS - 1;
                 const int y = nn / W8_W;
                 const int x = nn - y * W8_W;
-                lb[j] = 4 * y * FS + 3 * x;
+                lbw[j] = (4 * y * FS + 3 * x + (g == 1 ? 2 * FS + 2 : 0)) * 4;
             }
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int k = 4 * s + g;
-                koff[s] = k < 9 ? (k / 3) * FS + (k - 3 * (k / 3)) : 0;
-            }
-            float a0[3][3];
+            // selectors: low halves = part 1, high halves = part 2 of (even word, odd word); 0x0c bytes give zero
+            const unsigned sel_h0 = g == 0 ? 0x05040100u : (g == 1 ? 0x0c0c0100u : 0x0c0c0c0cu);
+            const unsigned sel_l0 = g == 0 ? 0x07060302u : (g == 1 ? 0x0c0c0302u : 0x0c0c0c0cu);
+            const unsigned sel_h = g == 0 ? 0x05040100u : 0x0c0c0c0cu;
+            const unsigned sel_l = g == 0 ? 0x07060302u : 0x0c0c0c0cu;
+            u32x4 a0[3][2];
+            const u32x4* A0 = reinterpret_cast<const u32x4*>(p.w0h) + lane;
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) a0[m][s] = p.w0a[(m * 3 + s) * 64 + lane];
-            const float ax0 = p.w0a[(mx * 3 + 0) * 64 + lane], ax1 = p.w0a[(mx * 3 + 1) * 64 + lane],
-                        ax2 = p.w0a[(mx * 3 + 2) * 64 + lane];
+                for (int pt = 0; pt < 2; ++pt) a0[m][pt] = A0[(m * 2 + pt) * 64];
             const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float post = p.inv_scale0 * (1.0f / 12.0f);
+            const char* fb = reinterpret_cast<const char*>(feat_w);
+            // B fragments of pooling-window member (OY, OX) of the position whose window base is at byte address LB
+#define C0_FRAG(LB, OY, OX, BH, BL)                                                                            \
+    {                                                                                                          \
+        unsigned w_[8];                                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                          \
+            w_[e] = *reinterpret_cast<const unsigned*>(fb + (LB) + (((OY) + e / 3) * FS + (OX) + e % 3) * 4);  \
+        BH[0] = __builtin_amdgcn_perm(w_[1], w_[0], sel_h0);                                                   \
+        BL[0] = __builtin_amdgcn_perm(w_[1], w_[0], sel_l0);                                                   \
+        _Pragma("unroll") for (int i = 1; i < 4; ++i) {                                                        \
+            BH[i] = __builtin_amdgcn_perm(w_[2 * i + 1], w_[2 * i], sel_h);                                    \
+            BL[i] = __builtin_amdgcn_perm(w_[2 * i + 1], w_[2 * i], sel_l);                                    \
+        }                                                                                                      \
+    }
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                const int ad0 = lb[j] + koff[0], ad1 = lb[j] + koff[1], ad2 = lb[j] + koff[2];
                 f32x4 s0 = zero, s1 = zero, s2 = zero;
                 if (!(p.debug & 1)) {
 #pragma unroll
-                    for (int wp = 0; wp < 6; ++wp) {
-                        f32x4 cc[2][3];
+                    for (int wi = 0; wi < 12; ++wi) {
+                        const int oy = wi / 3, ox = wi - 3 * oy;
+                        u32x4 bh, bl;
+                        C0_FRAG(lbw[j], oy, ox, bh, bl)
+                        f32x4 cc[3];
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int wi = 2 * wp + h, oy = wi / 3, ox = wi - 3 * oy;
-                            const float b0 = feat_s[ad0 + oy * FS + ox], b1 = feat_s[ad1 + oy * FS + ox],
-                                        b2 = feat_s[ad2 + oy * FS + ox];
-#pragma unroll
-                            for (int m = 0; m < 3; ++m) cc[h][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m][0], b0, zero, 0, 0, 0);
-#pragma unroll
-                            for (int m = 0; m < 3; ++m) cc[h][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m][1], b1, cc[h][m], 0, 0, 0);
-#pragma unroll
-                            for (int m = 0; m < 3; ++m) cc[h][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m][2], b2, cc[h][m], 0, 0, 0);
+                        for (int m = 0; m < 3; ++m) {
+                            cc[m] = zero;
+                            MF(a0[m][1], bh, cc[m]);
                         }
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            s0 += relu4(cc[h][0]);
-                            s1 += relu4(cc[h][1]);
-                            s2 += relu4(cc[h][2]);
-                        }
+                        for (int m = 0; m < 3; ++m) { MF(a0[m][0], bl, cc[m]); }
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) { MF(a0[m][0], bh, cc[m]); }
+                        s0 += relu4(cc[0]);
+                        s1 += relu4(cc[1]);
+                        s2 += relu4(cc[2]);
                     }
                 }
-                prev[j][0] = s0 * (1.0f / 12.0f);
-                prev[j][1] = s1 * (1.0f / 12.0f);
-                prev[j][2] = s2 * (1.0f / 12.0f);
+                prev[j][0] = s0 * post;
+                prev[j][1] = s1 * post;
+                prev[j][2] = s2 * post;
             }
             {
-                const int ad0 = lb[5] + koff[0], ad1 = lb[5] + koff[1], ad2 = lb[5] + koff[2];
                 f32x4 sx = zero;
                 if (!(p.debug & 1)) {
 #pragma unroll
-                    for (int oy = 0; oy < 4; ++oy)
-#pragma unroll
-                        for (int ox = 0; ox < 3; ++ox) {
-                            f32x4 cx = __builtin_amdgcn_mfma_f32_16x16x4f32(ax0, feat_s[ad0 + oy * FS + ox], zero, 0, 0, 0);
-                            cx = __builtin_amdgcn_mfma_f32_16x16x4f32(ax1, feat_s[ad1 + oy * FS + ox], cx, 0, 0, 0);
-                            cx = __builtin_amdgcn_mfma_f32_16x16x4f32(ax2, feat_s[ad2 + oy * FS + ox], cx, 0, 0, 0);
-                            sx += relu4(cx);
-                        }
+                    for (int wi = 0; wi < 12; ++wi) {
+                        const int oy = wi / 3, ox = wi - 3 * oy;
+                        u32x4 bh, bl;
+                        C0_FRAG(lbw[5], oy, ox, bh, bl)
+                        f32x4 cx = zero;
+                        if (mx == 0) { MF(a0[0][1], bh, cx); MF(a0[0][0], bl, cx); MF(a0[0][0], bh, cx); }
+                        else if (mx == 1) { MF(a0[1][1], bh, cx); MF(a0[1][0], bl, cx); MF(a0[1][0], bh, cx); }
+                        else { MF(a0[2][1], bh, cx); MF(a0[2][0], bl, cx); MF(a0[2][0], bh, cx); }
+                        sx += relu4(cx);
+                    }
                 }
-                prevx = sx * (1.0f / 12.0f);
+                prevx = sx * post;
             }
+#undef C0_FRAG
         }
         // every wave is done with the staged features: turn the region back into an all-zero map (halo cells included), then
         // write the pooled conv_0 output into its interior
@@ -425,6 +442,22 @@ hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------- host packing
+// conv_0 weight (45, 9) times `scale` -> [channel tile 3][part 2][lane 64][8 fp16]: cout = 16 m + (lane & 15), k-slot
+// 8 (lane >> 4) + j holds tap k for k < 9, zeros otherwise
+void pack_res8h_conv0(const float* wt, float scale, unsigned short* dst) {
+    for (int m = 0; m < 3; ++m)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int co = 16 * m + (lane & 15);
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * (lane >> 4) + j;
+                const float v = (k < 9 && co < R8_C) ? wt[co * 9 + k] * scale : 0.f;
+                const unsigned short h = f16_rne_host(v);
+                dst[((m * 2 + 0) * 64 + lane) * 8 + j] = h;
+                dst[((m * 2 + 1) * 64 + lane) * 8 + j] = f16_rne_host(v - f16_to_f_host(h));
+            }
+        }
+}
+
 // conv_i weight (45,45,3,3) times `scale` -> [k-step 14][channel tile 3][part 2][lane 64][8 fp16]:
 //   cout = 16 m + (lane & 15); block bi = 4 s + (lane >> 4): tap = bi / 6, input channels 8 (bi % 6) .. +7; bi >= 54: zeros
 void pack_res8h_layer(const float* wt, float scale, unsigned short* dst) {
