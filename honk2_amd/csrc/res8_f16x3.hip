@@ -261,30 +261,35 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
     float* bnt = c.mvec + 48;
     c.bnt = bnt;
 
-    const int tid = threadIdx.x;
-    c.tid = tid;
-    c.lane = tid & 63;
-    c.w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    c.g = c.lane >> 4;
-    c.pcol = c.lane & 15;
+    c.w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     c.mx = c.w < 2 ? c.w : 2;
-    const int w = c.w, g = c.g, pcol = c.pcol, mx = c.mx, lane = c.lane;
+    const int w = c.w, mx = c.mx;
 
-    for (int i = tid; i < BNT_WORDS; i += 256) bnt[i] = p.bn_tab[i];
-
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int nt = j < 5 ? 5 * w + j : 20;
-        const int n = 16 * nt + pcol;
-        const int nn = n < R8_NPOS ? n : R8_NPOS - 1;
-        const int y = nn / W8_W;
-        const int x = nn - y * W8_W;
-        c.qb[j] = ((y + 1) * R8_RS + x + 1) * CELL_B;
-    }
-    c.xvalid = w < 3 && (16 * 20 + pcol) < R8_NPOS;
+    for (int i = threadIdx.x; i < BNT_WORDS; i += 256) bnt[i] = p.bn_tab[i];
 
     for (int clip = blockIdx.x; clip < p.B; clip += gridDim.x) {
         __syncthreads();  // previous clip's tail has consumed red/mvec and the map
+
+        // Everything derived from the lane id is recomputed per clip from an opaque copy of it.  Otherwise the compiler
+        // hoists some 80 per-lane addresses and selectors out of this loop, keeps them alive across it and -- at 256
+        // registers -- spills them (7.9 GB of scratch reloads per 65 536 clips in the counters).
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        c.tid = tid;
+        c.lane = tid & 63;
+        c.g = c.lane >> 4;
+        c.pcol = c.lane & 15;
+        const int g = c.g, pcol = c.pcol, lane = c.lane;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int nt = j < 5 ? 5 * w + j : 20;
+            const int n = 16 * nt + pcol;
+            const int nn = n < R8_NPOS ? n : R8_NPOS - 1;
+            const int y = nn / W8_W;
+            const int x = nn - y * W8_W;
+            c.qb[j] = ((y + 1) * R8_RS + x + 1) * CELL_B;
+        }
+        c.xvalid = w < 3 && (16 * 20 + pcol) < R8_NPOS;
 
         // ---- stage the (101, 40) feature map as fp32 with a zero top row / left column, inside the idle map region
         {
