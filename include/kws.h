@@ -27,9 +27,10 @@
  *     thread-local human-readable message for the last failure on the calling thread.
  *   - a handle is bound to the HIP device that was current at kws_create and is not re-entrant
  *     (one in-flight call per handle); distinct handles are independent.
- *   - KWS_DTYPE_F32: results are fp32-accurate (fp32 accumulation everywhere).  Products are formed either by the
- *     fp32-input MFMA / fp32 VALU, or -- fused res8 -- on the bf16 matrix cores as six exact bf16 x bf16 partial
- *     products of three-way bf16 splits of both fp32 operands (error <= 2^-24 |ab|, i.e. at the fp32 rounding level).
+ *   - KWS_DTYPE_F32: results are fp32-accurate (fp32 accumulation everywhere).  Products are formed on the 16-bit matrix cores
+ *     from split fp32 operands: three exact fp16 x fp16 terms of two-part fp16 splits (weights pre-scaled by a power of two per
+ *     layer; error <= 3 * 2^-22 |ab|, measured as close to a float64 evaluation as an fp32 implementation; activations must
+ *     stay below 65504 in magnitude), or -- KWS_RES8_IMPL=bf16x6 -- six bf16 x bf16 terms of three-part bf16 splits.
  */
 #ifndef KWS_H_
 #define KWS_H_
