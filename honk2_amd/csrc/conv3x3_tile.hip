@@ -102,8 +102,10 @@ __device__ __forceinline__ void split4_f16(f32x4 x, u32x2 (&out)[2]) {
 // a1b2 a1b1 (six), the last three (KWS_DTYPE_BF16X3) or the last one (KWS_DTYPE_BF16)
 #define TMF6(A3, B3, C_)           \
     if (F16) {                     \
-        TMFH(A3[1], B3[0], C_);    \
-        TMFH(A3[0], B3[1], C_);    \
+        if (TERMS >= 3) {          \
+            TMFH(A3[1], B3[0], C_);\
+            TMFH(A3[0], B3[1], C_);\
+        }                          \
         TMFH(A3[0], B3[0], C_);    \
     } else {                       \
         if (TERMS == 6) {          \
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
     constexpr int CELL = NB * 16 * LP, PART = NB * 16;
     constexpr int GCELL = NB * 32;                  // global cell: NB*8 channels x 4 B
     constexpr int STEPS = (9 * NB + 3) / 4;
-    constexpr int NP = F16 ? 2 : (TERMS == 6 ? 3 : (TERMS == 3 ? 2 : 1));   // parts that take part in the products
+    constexpr int NP = F16 ? (TERMS >= 3 ? 2 : 1) : (TERMS == 6 ? 3 : (TERMS == 3 ? 2 : 1));   // parts that take part in the products
     constexpr int TILE_P = F16 ? T3_TILE_P_F16 : T3_TILE_P;
     constexpr int JT = TILE_P / 64;                 // position tiles per wave (5 / 3)
     constexpr int NQ = NB * 2;         // 4-channel quads per cell
@@ -357,6 +359,7 @@ static hipError_t launch_t3k(const TileConvParams& p, hipStream_t s) {
 
 template <int NB, int MT>
 static hipError_t launch_t3(const TileConvParams& p, hipStream_t s) {
+    if (p.f16 && p.terms == 1) return launch_t3k<NB, MT, 1, true>(p, s);
     if (p.f16) return launch_t3k<NB, MT, 3, true>(p, s);
     if (p.terms == 1) return launch_t3k<NB, MT, 1, false>(p, s);
     if (p.terms == 3) return launch_t3k<NB, MT, 3, false>(p, s);

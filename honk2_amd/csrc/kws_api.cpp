@@ -239,7 +239,7 @@ int build_resnet(kws_handle* h) {
         h->r8h_apk_host.assign(R8H_APK_SHORTS, 0);
         const char* impl = std::getenv("KWS_RES8_IMPL");
         h->res8_impl = impl && std::strcmp(impl, "fp32") == 0 ? 2 : (impl && std::strcmp(impl, "bf16x6") == 0 ? 1 : 0);
-        if (d.dtype != KWS_DTYPE_F32 && h->res8_impl == 0) h->res8_impl = 1;   // bf16x3 / bf16 modes live in the bf16 kernel
+        if ((d.dtype == KWS_DTYPE_BF16X3 || d.dtype == KWS_DTYPE_BF16) && h->res8_impl == 0) h->res8_impl = 1;   // bf16 kernel
     }
     return KWS_OK;
 }
@@ -311,11 +311,12 @@ int upload_packed(ConvLayer& L, const float* w, LwMode mode) {
     return rc;
 }
 
+void decode_mode(int mode, int& f16, int& terms);
+
 // one conv launch through whichever kernel the layer supports (geometry fields B/H/W already set in g)
 int launch_layer(const ConvLayer& L, const ConvGeom& g_in, ConvArgs a, hipStream_t s, int terms = 6) {
     ConvGeom g = g_in;
-    g.x_terms = terms;
-    g.x_f16 = terms == 6 ? 1 : 0;   // the fp32-accurate default runs on fp16 parts; bf16x3 / bf16 dtypes on bf16 parts
+    decode_mode(terms, g.x_f16, g.x_terms);
     g.x_inv_scale = g.x_f16 ? 1.0f / L.x_scale : 1.0f;
     if (L.use_x) {
         a.apk16 = g.x_f16 ? L.apk16h.as<unsigned short>() : L.apk16.as<unsigned short>();
@@ -436,7 +437,17 @@ ResnetShape resnet_shape(const kws_handle* h, int T) {
 
 int pad8(int c) { return (c + 7) / 8 * 8; }
 // bf16 product terms per fp32 product: 6 = fp32-accurate, 3 = KWS_DTYPE_BF16X3, 1 = plain bf16 operands
-int dtype_terms(int dtype) { return dtype == KWS_DTYPE_BF16X3 ? 3 : dtype == KWS_DTYPE_BF16 ? 1 : 6; }
+// matrix mode code passed down to the launchers: 6 = fp32-accurate default (two-part fp16 operands, three terms), 16 = plain
+// fp16 operands (KWS_DTYPE_F16), 3 = KWS_DTYPE_BF16X3, 1 = KWS_DTYPE_BF16 (bf16 parts), 66 = fp32-accurate on three-part bf16
+// operands, six terms (KWS_MATRIX_PARTS=bf16: no fp16 range limit)
+int dtype_terms(int dtype) {
+    static const bool bf16_parts = std::getenv("KWS_MATRIX_PARTS") && std::strcmp(std::getenv("KWS_MATRIX_PARTS"), "bf16") == 0;
+    return dtype == KWS_DTYPE_BF16X3 ? 3 : dtype == KWS_DTYPE_BF16 ? 1 : dtype == KWS_DTYPE_F16 ? 16 : (bf16_parts ? 66 : 6);
+}
+void decode_mode(int mode, int& f16, int& terms) {
+    f16 = (mode == 6 || mode == 16) ? 1 : 0;
+    terms = mode == 6 ? 3 : mode == 16 ? 1 : mode == 66 ? 6 : mode;
+}
 int ilog2(int d) { int l = 0; while ((1 << l) < d) ++l; return l; }
 
 // LDS-tiled 3x3 kernel usable for every conv_i of this ResNet?
@@ -558,7 +569,7 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
             tp.in = even ? Y : xc;
             tp.out = even ? xn : Y;
             tp.res = even ? xc : nullptr;
-            tp.f16 = d.dtype == KWS_DTYPE_F32 ? 1 : 0;   // the reduced-precision dtypes keep bf16 parts
+            decode_mode(terms, tp.f16, tp.terms);
             tp.apk16 = tp.f16 ? h->rconv[i].apk_t3h.as<unsigned short>() : h->rconv[i].apk16.as<unsigned short>();
             tp.inv_scale = tp.f16 ? 1.0f / h->rconv[i].t3h_scale : 1.0f;
             tp.border = h->rconv[i].has_border ? h->rconv[i].border_pad.as<float>() : nullptr;
@@ -566,7 +577,6 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
             tp.ld_in = ld_in; tp.ld_out = ld_out; tp.ld_res = ld_x;
             tp.Hs = (sh.H + dd - 1) / dd; tp.Ws = (sh.W + dd - 1) / dd;
             tp.total = nb * dd * dd * tp.Hs * tp.Ws;
-            tp.terms = terms;
             HIP_TRY(launch_conv3x3_tile(tp, C, s));
             if (even) {
                 std::swap(xc, xn);
@@ -706,6 +716,7 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 p.bn_tab = h->r8h_bn.as<float>(); p.out_w = h->out_w.as<float>(); p.out_b = h->out_b.as<float>();
                 for (int i = 0; i < R8_LAYERS; ++i) p.inv_scale[i] = 1.0f / h->r8h_scale[i];
                 p.B = B; p.T = T; p.F = h->d.freq; p.n_labels = h->d.n_labels; p.debug = dbg;
+                p.terms = h->d.dtype == KWS_DTYPE_F16 ? 1 : 3;
                 static const int r8_wgs = std::getenv("KWS_R8_WGS_PER_CU") ? std::atoi(std::getenv("KWS_R8_WGS_PER_CU")) : 2;
                 HIP_TRY(launch_res8h(p, std::min(B, r8_wgs * h->n_cu), s));
             } else if (h->res8_impl == 2) {
@@ -719,7 +730,7 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 h->last_plan = "res8_fused_bf16x6";
                 Res8xParams p{feat, logits, h->r8_w0a.as<float>(), h->r8x_apk.p, h->r8_bn.as<float>(),
                               h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq, h->d.n_labels, dbg,
-                              dtype_terms(h->d.dtype)};
+                              h->d.dtype == KWS_DTYPE_BF16X3 ? 3 : h->d.dtype == KWS_DTYPE_BF16 ? 1 : 6};
                 HIP_TRY(launch_res8x(p, std::min(B, 256), s));
             }
         } else {
@@ -761,8 +772,9 @@ const char* kws_last_error(void) { return g_err.c_str(); }
 int kws_create(const kws_model_desc* desc, kws_handle** out) {
     if (!desc || !out) return fail(KWS_EINVAL, "null argument");
     if (desc->struct_size != (int)sizeof(kws_model_desc)) return fail(KWS_EINVAL, "kws_model_desc size mismatch (ABI)");
-    if (desc->dtype != KWS_DTYPE_F32 && desc->dtype != KWS_DTYPE_BF16X3 && desc->dtype != KWS_DTYPE_BF16)
-        return fail(KWS_EUNSUPPORTED, "dtype must be KWS_DTYPE_F32, KWS_DTYPE_BF16X3 or KWS_DTYPE_BF16");
+    if (desc->dtype != KWS_DTYPE_F32 && desc->dtype != KWS_DTYPE_BF16X3 && desc->dtype != KWS_DTYPE_BF16 &&
+        desc->dtype != KWS_DTYPE_F16)
+        return fail(KWS_EUNSUPPORTED, "dtype must be one of KWS_DTYPE_F32 / BF16X3 / BF16 / F16");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) return fail(KWS_EHIP, "no HIP device available: the HIP path is mandatory, there is no CPU fallback");

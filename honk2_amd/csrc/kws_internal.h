@@ -167,6 +167,7 @@ struct Res8hParams {
     float inv_scale[R8_LAYERS];   // 2^-S per layer
     int B, T, F, n_labels;
     int debug;            // timing experiments only: 1 skip conv_0, 2 skip the MFMA loop
+    int terms;            // 3: fp32-accurate products; 1: plain fp16 operands (KWS_DTYPE_F16)
 };
 size_t res8h_lds_bytes();
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s);

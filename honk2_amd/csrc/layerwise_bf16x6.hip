@@ -73,8 +73,10 @@ __device__ __forceinline__ void split8_f16(const float (&x)[8], u32x4 (&out)[3])
 #define XMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
 #define XMF6(A3, B3, C_)            \
     if (F16) {                      \
-        XMFH(A3[1], B3[0], C_);     \
-        XMFH(A3[0], B3[1], C_);     \
+        if (TERMS >= 3) {           \
+            XMFH(A3[1], B3[0], C_); \
+            XMFH(A3[0], B3[1], C_); \
+        }                           \
         XMFH(A3[0], B3[0], C_);     \
     } else {                        \
         if (TERMS == 6) {           \
@@ -307,7 +309,8 @@ static hipError_t launch_x_mt(const ConvGeom& g, const ConvArgs& a, hipStream_t 
     const bool multi = pooled && g.pool_h * g.pool_w > 4;
 #define X_LAUNCH(KX_, T_, M_)                                                                                      \
     do {                                                                                                           \
-        if (g.x_f16) hipLaunchKernelGGL((conv_bf16x6_kernel<MT, KX_, 3, M_, true>), grid, dim3(256), 0, s, g, a);  \
+        if (g.x_f16 && g.x_terms == 1) hipLaunchKernelGGL((conv_bf16x6_kernel<MT, KX_, 1, M_, true>), grid, dim3(256), 0, s, g, a); \
+        else if (g.x_f16) hipLaunchKernelGGL((conv_bf16x6_kernel<MT, KX_, 3, M_, true>), grid, dim3(256), 0, s, g, a);  \
         else hipLaunchKernelGGL((conv_bf16x6_kernel<MT, KX_, T_, M_, false>), grid, dim3(256), 0, s, g, a);        \
     } while (0)
 #define X_LAUNCH_T(T_)                                         \

@@ -68,9 +68,11 @@ __device__ __forceinline__ void store_split(char* lds, int addr, f32x4 v) {
 
 #define MF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
 // three-term product, small terms first
-#define MF6(A2, B_, C_)   \
-    MF(A2[1], B_[0], C_); \
-    MF(A2[0], B_[1], C_); \
+#define MF6(A2, B_, C_)       \
+    if (TERMS >= 3) {         \
+        MF(A2[1], B_[0], C_); \
+        MF(A2[0], B_[1], C_); \
+    }                         \
     MF(A2[0], B_[0], C_);
 
 struct XCtx {
@@ -131,7 +133,7 @@ __device__ __forceinline__ void load_b(BFrag& b, const char* lds, int addr) {
         }                                                                             \
     }
 
-template <bool EVEN, bool LAST>
+template <int TERMS, bool EVEN, bool LAST>
 __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int layer, int clip, f32x4 (&prev)[5][3],
                                         f32x4& prevx) {
     const int g = c.g, mx = c.mx;
@@ -251,6 +253,7 @@ size_t res8h_lds_bytes() { return (size_t)X_LDS_BYTES; }
 // VGPR-accumulator MFMAs, which one wave can only issue at half rate (tools/mfma_dep_probe.cpp): alone in its k-loop a
 // workgroup does not fill the pipe.  Forcing AGPR accumulators splits the budget 128 / 128 and spills (18.2 ms); a
 // start-up stagger of the second workgroup changes nothing.
+template <int TERMS>   // 3: fp32-accurate; 1: plain fp16 operands (KWS_DTYPE_F16)
 __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     XCtx c;
@@ -424,25 +427,30 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, prevx);
         __syncthreads();
 
-        x_layer<false, false>(p, c, 0, clip, prev, prevx);
-        x_layer<true, false>(p, c, 1, clip, prev, prevx);
-        x_layer<false, false>(p, c, 2, clip, prev, prevx);
-        x_layer<true, false>(p, c, 3, clip, prev, prevx);
-        x_layer<false, false>(p, c, 4, clip, prev, prevx);
-        x_layer<true, true>(p, c, 5, clip, prev, prevx);
+        x_layer<TERMS, false, false>(p, c, 0, clip, prev, prevx);
+        x_layer<TERMS, true, false>(p, c, 1, clip, prev, prevx);
+        x_layer<TERMS, false, false>(p, c, 2, clip, prev, prevx);
+        x_layer<TERMS, true, false>(p, c, 3, clip, prev, prevx);
+        x_layer<TERMS, false, false>(p, c, 4, clip, prev, prevx);
+        x_layer<TERMS, true, true>(p, c, 5, clip, prev, prevx);
     }
 }
 
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)res8h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)res8h_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)res8h_lds_bytes());
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)res8h_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res8h_lds_bytes());
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (p.B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(res8h_kernel, dim3((unsigned)grid), dim3(256), res8h_lds_bytes(), s, p);
+    if (p.terms == 1)
+        hipLaunchKernelGGL(res8h_kernel<1>, dim3((unsigned)grid), dim3(256), res8h_lds_bytes(), s, p);
+    else
+        hipLaunchKernelGGL(res8h_kernel<3>, dim3((unsigned)grid), dim3(256), res8h_lds_bytes(), s, p);
     return hipGetLastError();
 }
 

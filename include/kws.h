@@ -60,8 +60,10 @@ enum { KWS_MODEL_NONE = 0, KWS_MODEL_RESNET = 1, KWS_MODEL_CNN = 2 };
  * throughput of the 6-term form.  Not argmax-exact against the fp32 reference on near-ties.
  * KWS_DTYPE_BF16: plain bf16 operands (weights and activations rounded to bf16 at the matrix operand, fp32 accumulate,
  * fp32 activations between layers, fp32 front end and first conv): BASELINE's bf16 configuration; logits agree with the fp32
- * reference to ~1e-2 at |logit| ~ 1. */
-enum { KWS_DTYPE_F32 = 0, KWS_DTYPE_BF16X3 = 1, KWS_DTYPE_BF16 = 2 };
+ * reference to ~1e-2 at |logit| ~ 1.
+ * KWS_DTYPE_F16: plain fp16 operands (BASELINE's fp16 configuration), same structure as KWS_DTYPE_BF16 with 11-bit operands:
+ * logits agree with the fp32 reference to ~1e-3 at |logit| ~ 1. */
+enum { KWS_DTYPE_F32 = 0, KWS_DTYPE_BF16X3 = 1, KWS_DTYPE_BF16 = 2, KWS_DTYPE_F16 = 3 };
 
 typedef struct kws_conv_desc {
     int32_t out_channels;

@@ -136,6 +136,26 @@ def test_plain_bf16_mode(torch_cuda, fname):
     assert np.abs(x3 - want).max() < err         # the three-term mode sits between bf16 and the default
 
 
+@pytest.mark.parametrize("fname", ["model_cnn__cnn-trad-pool2.npz", "model_resnet__res15.npz", "model_resnet__res8.npz"])
+def test_plain_fp16_mode(torch_cuda, fname):
+    """`dtype: "fp16"` (BASELINE configs[4]: cnn-trad-pool2 fp16): operands rounded to fp16 at the matrix cores (weights carry a
+    power-of-two scale), fp32 accumulation.  Tolerance 5e-3 at |logit| ~ 1 as SURVEY.md Appendix C prescribes for fp16,
+    argmax compared where the reference's margin exceeds twice the tolerance; it must sit between bf16 and the default."""
+    torch = torch_cuda
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    x = torch.from_numpy(feats).cuda()
+    got = _build(torch, name, dict(cfg, dtype="fp16"), sd)(x).cpu().numpy()
+    want = z["logits"]
+    tol = 5e-3 * max(1.0, float(np.abs(want).max()))
+    err = np.abs(got - want).max()
+    assert 1e-6 < err < tol, (tag, err)
+    top = np.sort(want, axis=1)
+    clear = (top[:, -1] - top[:, -2]) > 2 * tol
+    assert (got.argmax(1) == want.argmax(1))[clear].all()
+    bf = _build(torch, name, dict(cfg, dtype="bf16"), sd)(x).cpu().numpy()
+    assert err < np.abs(bf - want).max()
+
+
 def test_res8_fused_equals_layerwise_and_oracle_on_a_larger_batch(torch_cuda, monkeypatch):
     torch = torch_cuda
     from oracle import models, weights
