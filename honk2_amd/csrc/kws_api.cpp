@@ -441,7 +441,8 @@ int pad8(int c) { return (c + 7) / 8 * 8; }
 // fp16 operands (KWS_DTYPE_F16), 3 = KWS_DTYPE_BF16X3, 1 = KWS_DTYPE_BF16 (bf16 parts), 66 = fp32-accurate on three-part bf16
 // operands, six terms (KWS_MATRIX_PARTS=bf16: no fp16 range limit)
 int dtype_terms(int dtype) {
-    static const bool bf16_parts = std::getenv("KWS_MATRIX_PARTS") && std::strcmp(std::getenv("KWS_MATRIX_PARTS"), "bf16") == 0;
+    const char* mp = std::getenv("KWS_MATRIX_PARTS");   // read per call on purpose (tests flip it)
+    const bool bf16_parts = mp && std::strcmp(mp, "bf16") == 0;
     return dtype == KWS_DTYPE_BF16X3 ? 3 : dtype == KWS_DTYPE_BF16 ? 1 : dtype == KWS_DTYPE_F16 ? 16 : (bf16_parts ? 66 : 6);
 }
 void decode_mode(int mode, int& f16, int& terms) {

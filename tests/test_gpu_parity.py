@@ -193,6 +193,20 @@ def test_alternative_layerwise_kernels_agree(torch_cuda, monkeypatch, fname, imp
     assert (got.argmax(1) == z["logits"].argmax(1)).all()
 
 
+@pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_cnn__cnn-tpool2.npz"])
+def test_range_free_bf16_parts_for_the_layerwise_kernels(torch_cuda, monkeypatch, fname):
+    """KWS_MATRIX_PARTS=bf16: fp32-accurate products from six bf16 terms (no fp16 range limit) instead of three fp16 terms."""
+    torch = torch_cuda
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    x = torch.from_numpy(feats).cuda()
+    a = _build(torch, name, cfg, sd)(x).cpu().numpy()
+    monkeypatch.setenv("KWS_MATRIX_PARTS", "bf16")
+    b = _build(torch, name, cfg, sd)(x).cpu().numpy()
+    for y in (a, b):
+        assert np.abs(y - z["logits"]).max() < LOGIT_TOL and (y.argmax(1) == z["logits"].argmax(1)).all()
+    assert np.abs(a - b).max() < 2e-5 and not np.array_equal(a, b)
+
+
 def test_tiled_resnet_on_odd_shapes_and_unsupported_widths(torch_cuda):
     """The tiled 3x3 kernel on shapes no shipped config has: T not a multiple of anything, dilation reaching past the map,
     batches that end inside a tile, pooling; and a channel count it does not cover (falls back to the generic kernels)."""
