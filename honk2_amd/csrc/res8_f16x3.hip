@@ -13,8 +13,11 @@
 //     fp32 rounding of the sum) but not for weights (|w| ~ 0.05).  Weights are therefore scaled by a power of two per layer
 //     (max |w| * 2^S in [128, 256)) before the split and the accumulator is scaled back by 2^-S -- exact, and free: the
 //     factor is folded into the BatchNorm scale (odd layers) or into the FMA that adds the residual (even layers).
-//     Activations must stay below 65 504 in magnitude (log-mel features are <= ~30, BatchNorm outputs of trained models
-//     O(10)); KWS_RES8_IMPL=bf16x6 selects the range-free six-term kernel.
+//     fp16 overflows at 65 504.  Trained models stay at O(10), but nothing in the reference forbids more (a channel with a tiny
+//     running variance multiplies by 300): before a map is written the workgroup takes its maximum magnitude and, above 2^14,
+//     stores it scaled down by a power of two that the consumer multiplies back (range guard below; a test drives logits to
+//     4e8 through it).  Only the input features themselves must stay below 65 504 (log-mel features are <= ~30);
+//     KWS_RES8_IMPL=bf16x6 selects the six-term bf16 kernel, which has fp32's range everywhere.
 //   * LDS holds the map as [384 cells][2 parts][48 channels] fp16: 192 B per cell, 72 KB instead of 108; B fragments are
 //     two ds_read_b128 per position tile; the fp32 -> 2 x fp16 split happens once per output element in the epilogue.
 //   conv_0 (K = 9) keeps the fp32-input MFMA path.
@@ -85,6 +88,40 @@ struct XCtx {
     bool xvalid;
 };
 
+// fp16 range guard.  Activations go to LDS as fp16 pairs, so a value beyond 65504 would overflow.  Before a layer's output is
+// written, the workgroup takes the maximum magnitude of the whole map (one value per wave through LDS, riding on the barrier
+// that is there anyway) and, only if it exceeds 2^14, stores the map scaled down by the power of two that brings it back;
+// the consumer multiplies its accumulators by the same power of two (exact both ways).  Trained models never get there.
+// magnitudes are compared as bit patterns (monotone for non-negative floats); six DPP steps leave the wave's maximum in lane
+// 63 (quad swaps, half-row and row mirrors, then the two row broadcasts of GFX9)
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));   // row_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));   // row_bcast15 -> rows 1, 3
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));   // row_bcast31 -> rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// one slot per wave; consecutive guards alternate between two groups of four so that a group is never written while the other
+// workgroup members may still be reading it (a full barrier lies between a write and the next write of the same group)
+__device__ __forceinline__ void guard_push(unsigned* group, int w, int lane, float amax) {
+    const unsigned m = wave_umax(__builtin_bit_cast(unsigned, amax));
+    if (lane == 0) group[w] = m;
+}
+__device__ __forceinline__ float guard_read(const unsigned* group) {
+    return __builtin_bit_cast(float, max(max(group[0], group[1]), max(group[2], group[3])));
+}
+__device__ __forceinline__ int range_shift(float mx) {   // 0 for mx <= 2^14 (and for NaN), else ceil(log2(mx)) - 14
+    int e = 0;
+    if (mx > 16384.f) {
+        (void)frexpf(mx, &e);        // mx = f * 2^e, f in [0.5, 1)
+        e -= 14;
+        e = e > 100 ? 100 : e;       // inf: give up gracefully (the values were not finite anyway)
+    }
+    return e;
+}
+
 struct AFrags {
     u32x4 a[3][2];   // [channel tile][part]; the extra position tile uses a[mx] (mx is wave-uniform)
 };
@@ -135,7 +172,7 @@ __device__ __forceinline__ void load_b(BFrag& b, const char* lds, int addr) {
 
 template <int TERMS, bool EVEN, bool LAST>
 __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int layer, int clip, f32x4 (&prev)[5][3],
-                                        f32x4& prevx) {
+                                        f32x4& prevx, int& shift) {
     const int g = c.g, mx = c.mx;
     f32x4 acc[5][3], accx;
 #pragma unroll
@@ -170,7 +207,9 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
     //      weight scale 2^S; 2^-S rides on the residual FMA (even layers) or is already folded into the BatchNorm scale of
     //      the table (odd layers).
     const float* bt = c.bnt + layer * 96 + 4 * g;
-    const float inv = p.inv_scale[layer];
+    const float up = shift > 0 ? ldexpf(1.f, shift) : 1.f;   // undo the range guard of the map this layer read (uniform)
+    const float inv = p.inv_scale[layer] * up;
+    float amax = 0.f;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(bt + 16 * m);
@@ -183,8 +222,11 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
                 if (EVEN) {
                     v = fmaf(v, inv, prev[j][m][r]);
                     prev[j][m][r] = v;
+                } else if (shift > 0) {
+                    v *= up;
                 }
                 acc[j][m][r] = fmaf(v, sc[r], sh[r]);
+                amax = fmaxf(amax, fabsf(acc[j][m][r]));
             }
     }
     {
@@ -196,13 +238,27 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
             if (EVEN) {
                 v = fmaf(v, inv, prevx[r]);
                 prevx[r] = v;
+            } else if (shift > 0) {
+                v *= up;
             }
             accx[r] = fmaf(v, sc[r], sh[r]);
+            if (c.xvalid) amax = fmaxf(amax, fabsf(accx[r]));
         }
     }
+    unsigned* const ggrp = reinterpret_cast<unsigned*>(c.red) + 4 * ((layer + 1) & 1);   // the reduction buffer is idle until the tail
+    if (!LAST) guard_push(ggrp, c.w, c.lane, amax);
 
     __syncthreads();  // every wave has finished reading this layer's input map
     if (!LAST) {
+        shift = __builtin_amdgcn_readfirstlane(range_shift(guard_read(ggrp)));   // uniform
+        if (shift > 0) {
+            const float down = ldexpf(1.f, -shift);
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) acc[j][m] *= down;
+            accx *= down;
+        }
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
@@ -417,22 +473,39 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         }
         // every wave is done with the staged features: turn the region back into an all-zero map (halo cells included), then
         // write the pooled conv_0 output into its interior
+        int shift;   // range guard of the map the next layer reads
+        {
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) amax = fmaxf(amax, prev[j][m][r]);   // pooled ReLU outputs: >= 0
+            if (c.xvalid) amax = fmaxf(fmaxf(amax, prevx[0]), fmaxf(fmaxf(prevx[1], prevx[2]), prevx[3]));
+            guard_push(reinterpret_cast<unsigned*>(c.red), w, lane, amax);   // group 0; layer l uses group (l + 1) & 1
+        }
         __syncthreads();
         for (int i = tid; i < MAP_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(ldsb)[i] = (u32x4){0u, 0u, 0u, 0u};
+        shift = __builtin_amdgcn_readfirstlane(range_shift(guard_read(reinterpret_cast<const unsigned*>(c.red))));
         __syncthreads();
+        {
+            const float down = shift > 0 ? ldexpf(1.f, -shift) : 1.f;
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
+            for (int j = 0; j < 5; ++j)
 #pragma unroll
-            for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + (16 * m + 4 * g) * 2, prev[j][m]);
-        if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, prevx);
+                for (int m = 0; m < 3; ++m)
+                    store_split(c.lds, c.qb[j] + (16 * m + 4 * g) * 2, shift > 0 ? prev[j][m] * down : prev[j][m]);
+            if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, shift > 0 ? prevx * down : prevx);
+        }
         __syncthreads();
 
-        x_layer<TERMS, false, false>(p, c, 0, clip, prev, prevx);
-        x_layer<TERMS, true, false>(p, c, 1, clip, prev, prevx);
-        x_layer<TERMS, false, false>(p, c, 2, clip, prev, prevx);
-        x_layer<TERMS, true, false>(p, c, 3, clip, prev, prevx);
-        x_layer<TERMS, false, false>(p, c, 4, clip, prev, prevx);
-        x_layer<TERMS, true, true>(p, c, 5, clip, prev, prevx);
+        x_layer<TERMS, false, false>(p, c, 0, clip, prev, prevx, shift);
+        x_layer<TERMS, true, false>(p, c, 1, clip, prev, prevx, shift);
+        x_layer<TERMS, false, false>(p, c, 2, clip, prev, prevx, shift);
+        x_layer<TERMS, true, false>(p, c, 3, clip, prev, prevx, shift);
+        x_layer<TERMS, false, false>(p, c, 4, clip, prev, prevx, shift);
+        x_layer<TERMS, true, true>(p, c, 5, clip, prev, prevx, shift);
     }
 }
 

@@ -255,6 +255,26 @@ def test_three_fused_res8_kernels_agree_and_are_fp32_accurate(torch_cuda, monkey
         assert np.abs(ys[plan] - exact).max() <= 2.0 * err_fp32_impl + 1e-7, (plan, np.abs(ys[plan] - exact).max(), err_fp32_impl)
 
 
+def test_fused_res8_fp16_range_guard(torch_cuda):
+    """A channel whose running variance is tiny multiplies activations by hundreds per layer: logits reach 1e8 and the maps
+    leave fp16's range.  The fused kernel stores such maps scaled by a power of two and scales back in the consumer, so the
+    result must still match fp32 arithmetic to rounding error."""
+    torch = torch_cuda
+    from oracle import models, weights
+    cfg = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 12}
+    sd = weights.make_state_dict("ResNet", cfg, seed=5)
+    for k in sd:
+        if k.endswith("running_var"):
+            sd[k] = np.full_like(sd[k], 2e-4)
+    feats = weights.make_features(300, seed=9)
+    model = _build(torch, "ResNet", cfg, sd)
+    got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert model.plan_name() == "res8_fused"
+    want = models.forward_torch("ResNet", cfg, sd, feats).numpy()
+    assert np.abs(want).max() > 1e6 and np.isfinite(got).all()
+    assert np.abs(got - want).max() < 2e-6 * np.abs(want).max()
+
+
 def test_wav_to_logits_end_to_end(torch_cuda):
     torch = torch_cuda
     from oracle import frontend, models, weights
