@@ -1,0 +1,540 @@
+// MFCC front end on the fp16 matrix cores (default): wav -> 2*ln(mel power).  Persistent workgroups (two per CU) walk
+// the units (clip, 112-frame chunk).
+//
+// Same algorithm and same twice-folded DFT as frontend.hip (reference utils/audio_processor.py:18-30, looped per clip
+// by data_loader/audio_data_loader.py:23-35), but the four 64 x 120 GEMMs run as three-term fp16
+// products on v_mfma_f32_16x16x32_f16 (the scheme of res8_f16x3.hip): 336 MFMAs of 16 cycles per wave and unit instead
+// of 840 fp32-input MFMAs of 32 cycles.
+//   * A = cos / sin table x 2^7, split on the host into two fp16 parts, in fragment order; a wave streams its GEMM's
+//     fragments of the next k-step (K = 120 -> 4 steps of 32) from L2 while it works on the current one.
+//   * B = the folded, windowed samples  hj*(x[j] +- x[480-j]) +- (1-hj)*(x[240-j] +- x[240+j]), built in fp32 exactly
+//     as in frontend.hip, scaled by a per-unit power of two (2^13 for |x| < 2, less for louder input, so the fp16
+//     range cannot overflow whatever the samples are), split into two fp16 parts in registers.  A lane's eight k-slots
+//     are eight consecutive j, so the four operand streams are 128-bit LDS reads: two for each forward stream, two plus
+//     one word for each mirrored stream (LDS index = i + 4*floor(i/160): 16-byte blocks never straddle the padding).
+//     Tile column n holds frame fcol(n) -- even frames on lanes 0-3 / 12-15, odd ones on lanes 4-11 -- which makes the
+//     16-lane groups a ds_read_b128 is served in conflict-free.  The k order is free, so column j = 0 (weight 0) and
+//     columns 121..127 (weight 0) simply read whatever finite samples sit there.
+//   * |X|^2 goes to an LDS tile P[bin][frame] over the dead sample image (each cell has one Re and one Im owner); the
+//     mel stage runs with lane = frame (conflict-free rows) over packed non-zero taps, two bands per step; log and x2
+//     happen on the way out through a transposed tile so that the stores are whole rows.
+//   * Latency: the next unit's samples are requested (buffer loads, 76 registers the accumulators no longer need)
+//     before the mel stage and written to LDS after the output tile has been read; the unit's rows are stored last,
+//     because waiting for loads would otherwise wait for younger stores (one vmcnt).
+//   Inputs whose rows are not 16-byte aligned, and filterbanks that do not fit the LDS tables, take frontend.hip.
+#include "kws_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace kws {
+
+namespace {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XS = 164;                                        // LDS words per hop: 160 samples + 4
+constexpr int X_LEN = 160 * (FE_FRAMES - 1) + FE_NFFT;         // staged samples: 114 hop blocks
+constexpr int X_WORDS = X_LEN + 4 * ((X_LEN + 159) / 160);
+constexpr int TILE_WORDS = 16 * XS;                            // LDS words between consecutive 16-frame tiles
+constexpr int HW_WORDS = 256;                                  // h[j], h[240-j] for j = 0..127
+constexpr float A_SCALE = 128.f;
+constexpr int PS = 118;                                        // row stride (words) of the power tile P[bin][frame]
+constexpr int P_ROWS = 120;                                    // bins the mel stage may read (FE16_MAX_BIN)
+constexpr int OUT_STRIDE = 41;                                 // transposed output tile [frame][band]
+constexpr int OUT_OFF = P_ROWS * PS;
+constexpr int IMG_WORDS = X_WORDS > OUT_OFF + FE_FRAMES * OUT_STRIDE ? X_WORDS : OUT_OFF + FE_FRAMES * OUT_STRIDE;
+constexpr int CONST_WORDS = FE16_CONST_WORDS;
+}  // namespace
+
+__device__ __forceinline__ int fx_idx(int i) { return i + 4 * (i / 160); }
+
+// phase timestamps for tools/fe_phases.py: build with -DFE16_TIMING (they overwrite part of the feature rows)
+#ifdef FE16_TIMING
+#define FE16_TS_DECL unsigned long long ts[8];
+#define FE16_TS(i) ts[i] = __builtin_readcyclecounter();
+#else
+#define FE16_TS_DECL
+#define FE16_TS(i)
+#endif
+
+// MODE: 0 = fp32 samples, 1 = 16-bit PCM, 2 = PCM + additive noise clip
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* hw = lds + IMG_WORDS;                                     // [window 256][mel taps][band table]: FE16_CONST_WORDS
+    float* taps = hw + HW_WORDS;
+    int* band = reinterpret_cast<int*>(taps + FE16_MAX_TAPS);
+    unsigned* red = reinterpret_cast<unsigned*>(hw + CONST_WORDS);
+    const int tid0 = threadIdx.x;
+    const int n = p.n_samples;
+    const int nunits = p.B * p.chunks;                               // a unit = (clip, 112-frame chunk)
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+    // ---- constants (window, packed mel taps, band table): once per workgroup
+#pragma unroll
+    for (int i = 0; i < (CONST_WORDS + 255) / 256; ++i)
+        if (i * 256 + tid0 < CONST_WORDS) hw[i * 256 + tid0] = p.consts16[i * 256 + tid0];
+
+    // ---- sample loads of a unit, issued without waiting.  Padded index q of the chunk is sample org + q.  Thread
+    //      (bs, off) = (tid / 40, tid % 40), tid < 240, owns group `off` (four samples) of hop block 6 * it + bs in
+    //      iteration it: 19 iterations cover the image's 114 blocks exactly, the LDS address is a per-thread base + an
+    //      immediate and the global offset a per-thread base + a scalar (buffer loads: groups outside the clip
+    //      return 0 and are not stored).  The <= 60 groups of the reflected head and the <= 61 of the tail that
+    //      existing frames reach are re-read element-wise by threads 0..123 ("edge groups").  Groups past that belong
+    //      to frames beyond the clip's end, whose columns are never stored: they are not staged at all.  The loads of
+    //      unit i+1 are issued before the mel stage of unit i and land in registers the accumulators no longer need.
+    constexpr int len4 = X_LEN / 4;
+    constexpr int iters = X_LEN / 160 / 6;
+    static_assert(iters * 6 * 160 == X_LEN, "19 iterations x 6 hop blocks");
+    unsigned raw[iters][MODE == 0 ? 4 : (MODE == 1 ? 2 : 6)];   // fp32: four samples; PCM: four int16 [, four noise samples]
+    unsigned eraw[4][MODE == 2 ? 2 : 1];              // edge group: sample bits [, noise bits] per element
+    auto edge_group = [&](int tid, int t0, int org) -> int {   // padded group this thread re-reads element-wise, or -1
+        const int qt = (n - org) >> 2;                // first group that reaches past the clip's end
+        int qe = -1;
+        if (tid < 60) qe = t0 == 0 ? tid : -1;
+        else if (tid < 124) qe = qt + tid - 60;
+        return (qe >= 0 && qe < len4 && (org + 4 * qe < 0 || org + 4 * qe + 3 >= n)) ? qe : -1;
+    };
+    auto issue = [&](int unit, int tid) {
+        const int clip = unit / p.chunks;
+        const int t0 = (unit - clip * p.chunks) * FE_FRAMES;
+        const int org = 160 * t0 - FE_NFFT / 2;
+        const size_t cbase = (size_t)clip * p.clip_stride;
+        const int bs = tid / 40;
+        const int g0 = org + 160 * bs + 4 * (tid - 40 * bs);      // first sample of this thread's group in iteration 0
+        const int qe = edge_group(tid, t0, org);
+        int ex[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int sx = org + 4 * max(qe, 0) + e;
+            sx = sx < 0 ? -sx : sx;
+            sx = sx >= n ? 2 * (n - 1) - sx : sx;
+            ex[e] = max(0, min(sx, n - 1));
+        }
+        if (MODE == 0) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wav + cbase), 0, n * 4, 0x00020000);
+#pragma unroll
+            for (int it = 0; it < iters; ++it) {
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 4 * g0 + 3840 * it, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) raw[it][e] = v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) eraw[e][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * ex[e], 0, 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(p.pcm + cbase), 0, n * 2, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((MODE == 2 ? p.noise : p.wav) + cbase), 0, n * 4, 0x00020000);
+#pragma unroll
+            for (int it = 0; it < iters; ++it) {
+                const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, 2 * g0 + 1920 * it, 0, 0));
+                raw[it][0] = v[0];
+                raw[it][1] = v[1];
+                if (MODE == 2) {
+                    const u32x4 z = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, 4 * g0 + 3840 * it, 0, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) raw[it][(MODE == 2 ? 2 : 0) + e] = z[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                eraw[e][0] = (unsigned)(int)(short)__builtin_amdgcn_raw_buffer_load_b16(rs, 2 * ex[e], 0, 0);
+                if (MODE == 2) eraw[e][MODE == 2 ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b32(rz, 4 * ex[e], 0, 0);
+            }
+        }
+    };
+    auto finish = [&](float v, unsigned zbits) -> float {
+#pragma clang fp contract(off)   // two roundings, like numpy's `data += noise * noise_pct` in float32 (no FMA)
+        if (MODE == 2) {
+            const float t = __builtin_bit_cast(float, zbits) * p.noise_pct;
+            v = v + t;
+        }
+        return v;
+    };
+
+    // ---- write a unit's (pre-loaded) reflect-padded samples to the LDS image and reduce max |x| per wave
+    auto stage = [&](int unit, int tid) {
+        const int lane = tid & 63;
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int clip = unit / p.chunks;
+        const int t0 = (unit - clip * p.chunks) * FE_FRAMES;
+        const int org = 160 * t0 - FE_NFFT / 2;
+        const int bs = tid / 40;
+        const int off = tid - 40 * bs;
+        const int g0 = org + 160 * bs + 4 * off;
+        float* lbase = lds + XS * bs + 4 * off;
+        float mxf = 0.f;
+        auto put = [&](float* dst, f32x4 v) {
+            *reinterpret_cast<f32x4*>(dst) = v;
+            mxf = __builtin_fmaxf(__builtin_fmaxf(mxf, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+            mxf = __builtin_fmaxf(__builtin_fmaxf(mxf, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+        };
+        constexpr bool is_pcm = MODE != 0;
+#pragma unroll
+        for (int it = 0; it < iters; ++it) {
+            const int s0 = g0 + 960 * it;
+            if (tid < 240 && s0 >= 0 && s0 + 3 < n) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = is_pcm ? finish((float)(short)(raw[it][(e >> 1) & (MODE ? 1 : 3)] >> (16 * (e & 1))) * (1.0f / 32768.0f), MODE == 2 ? raw[it][(MODE == 2 ? 2 : 0) + e] : 0u)
+                                  : __builtin_bit_cast(float, raw[it][MODE == 0 ? e : 0]);
+                put(lbase + 6 * XS * it, v);
+            }
+        }
+        const int qe = edge_group(tid, t0, org);
+        if (qe >= 0) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = is_pcm ? finish((float)(int)eraw[e][0] * (1.0f / 32768.0f), eraw[e][MODE == 2 ? 1 : 0]) : __builtin_bit_cast(float, eraw[e][0]);
+            put(lds + fx_idx(4 * qe), v);
+        }
+        unsigned v = __builtin_bit_cast(unsigned, mxf);       // non-negative floats order like their bit patterns
+        // wave maximum in six DPP steps (quad swaps, half-row and row mirrors, the two row broadcasts): lane 63 holds it
+        v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
+        v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
+        v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
+        v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));
+        v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));
+        v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));
+        if (lane == 63) red[w] = v;
+    };
+
+    int unit = blockIdx.x;
+    if (unit < nunits) {
+        issue(unit, tid0);
+        stage(unit, tid0);
+    }
+#pragma unroll 1
+    for (; unit < nunits; unit += gridDim.x) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));      // lane-derived values are recomputed per unit instead of living across the loop
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+    const int pcol = lane & 15;
+    const int clip = unit / p.chunks;
+    const int chunk = unit - clip * p.chunks;
+    const int t0 = chunk * FE_FRAMES;
+    const int nfr = min(FE_FRAMES, p.T - t0);
+    FE16_TS_DECL
+    FE16_TS(0)
+
+    // ---- this wave's A fragments of k-step 0 (in flight during the staging below)
+    const u32x4* tab = static_cast<const u32x4*>(p.dft16) + (size_t)w * 4 * 8 * 64 + lane;
+    u32x4 an[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        an[m][0] = tab[(2 * m) * 64];
+        an[m][1] = tab[(2 * m + 1) * 64];
+    }
+
+    FE16_TS(1)
+    __syncthreads();
+    FE16_TS(2)
+
+    // ---- power-of-two scale of the B operand: |b| <= 2 max|x| must stay below 2^15 after scaling
+    const unsigned mxall = max(max(red[0], red[1]), max(red[2], red[3]));
+    const int ex = max((int)(mxall >> 23) - 127, 0);
+    const float b_scale = __builtin_bit_cast(float, (unsigned)(127 + 13 - ex) << 23);
+    const float post = __builtin_bit_cast(float, (unsigned)(127 - 20 + ex) << 23);   // 1 / (b_scale * A_SCALE)
+
+    f32x4 acc[4][FE_NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < FE_NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float sgn = w >= 2 ? -1.f : 1.f;                   // s: Re rows use sums, Im rows differences
+    const float tsg = (w == 1 || w == 2) ? -1.f : 1.f;       // t: sign of the (240-j) half
+    // column n of a tile is frame fr(n): the 16-lane groups a ds_read_b128 is served in pair lanes 0-3 / 12-15 of one
+    // k-group with lanes 4-11 of the next (8 words further on); with even frames on the former and odd frames on the
+    // latter the 16 lanes of a group start in 16 different 4-bank slots
+    const int fcol = pcol < 4 ? 2 * pcol : (pcol < 12 ? 2 * pcol - 7 : 2 * pcol - 16);
+    const int fb = XS * fcol;
+
+    // ---- k-loop, software-pipelined by hand: the B fragment of step idx + 1 (LDS reads, fold, window, split: ~44
+    //      VALU) is built in the shadow of the 12 MFMAs of step idx.  (Explicit one-MFMA-to-four-VALU scheduling
+    //      groups were tried: no faster, and the group solver's compile time explodes on a block this size.)
+    struct KStep {
+        int pa, pd, pb, pbs, pc, pcs;
+        float hj[8], hc[8];
+    };
+    auto setup = [&](int s, KStep& k) {
+        const int j0 = 32 * s + 8 * g;
+        k.pa = fb + j0;
+        k.pd = fb + 240 + j0 + (240 + j0 >= 320 ? 8 : 4);
+        k.pb = fb + 472 - j0 + 8;
+        k.pbs = fb + 480 - j0 + 8 - (j0 == 0 ? 1 : 0);
+        k.pc = fb + 232 - j0 + (232 - j0 >= 160 ? 4 : 0);
+        k.pcs = fb + 240 - j0 + (240 - j0 >= 160 ? 4 : 0);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(hw + j0), h1 = *reinterpret_cast<const f32x4*>(hw + j0 + 4);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(hw + 128 + j0), c1 = *reinterpret_cast<const f32x4*>(hw + 132 + j0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            k.hj[e] = h0[e] * b_scale;
+            k.hj[4 + e] = h1[e] * b_scale;
+            k.hc[e] = c0[e] * (b_scale * tsg);
+            k.hc[4 + e] = c1[e] * (b_scale * tsg);
+        }
+    };
+    auto build = [&](const KStep& k, int j, u32x4& bh, u32x4& bl) {
+        const float* base = lds + j * TILE_WORDS;
+        const f32x4 A0 = *reinterpret_cast<const f32x4*>(base + k.pa), A1 = *reinterpret_cast<const f32x4*>(base + k.pa + 4);
+        const f32x4 D0 = *reinterpret_cast<const f32x4*>(base + k.pd), D1 = *reinterpret_cast<const f32x4*>(base + k.pd + 4);
+        const f32x4 M0 = *reinterpret_cast<const f32x4*>(base + k.pb), M1 = *reinterpret_cast<const f32x4*>(base + k.pb + 4);
+        const f32x4 N0 = *reinterpret_cast<const f32x4*>(base + k.pc), N1 = *reinterpret_cast<const f32x4*>(base + k.pc + 4);
+        const float MS = base[k.pbs], NS = base[k.pcs];
+        const float xa[8] = {A0[0], A0[1], A0[2], A0[3], A1[0], A1[1], A1[2], A1[3]};
+        const float xd[8] = {D0[0], D0[1], D0[2], D0[3], D1[0], D1[1], D1[2], D1[3]};
+        const float xb[8] = {MS, M1[3], M1[2], M1[1], M1[0], M0[3], M0[2], M0[1]};
+        const float xc[8] = {NS, N1[3], N1[2], N1[1], N1[0], N0[3], N0[2], N0[1]};
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2 u = {fmaf(sgn, xb[e], xa[e]), fmaf(sgn, xb[e + 1], xa[e + 1])};
+            const f32x2 v = {fmaf(sgn, xd[e], xc[e]), fmaf(sgn, xd[e + 1], xc[e + 1])};
+            const f32x2 q = (f32x2){k.hc[e], k.hc[e + 1]} * v;
+            const f32x2 b = __builtin_elementwise_fma((f32x2){k.hj[e], k.hj[e + 1]}, u, q);
+            const f16x2 h = {(_Float16)b[0], (_Float16)b[1]};
+            const unsigned hp = __builtin_bit_cast(unsigned, h);
+            float r0, r1;   // b - h, the fp16 operand read straight from its half of the packed register
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(b[0]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(b[1]));
+            const f16x2 l = {(_Float16)r0, (_Float16)r1};
+            bh[e >> 1] = hp;
+            bl[e >> 1] = __builtin_bit_cast(unsigned, l);
+        }
+    };
+    {
+        KStep ks;
+        setup(0, ks);
+        u32x4 bh_c, bl_c;
+        build(ks, 0, bh_c, bl_c);
+        u32x4 a[4][2];
+#pragma unroll
+        for (int idx = 0; idx < 4 * FE_NT; ++idx) {
+            const int s = idx / FE_NT, j = idx - s * FE_NT;
+            if (j == 0) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    a[m][0] = an[m][0];
+                    a[m][1] = an[m][1];
+                }
+                if (s + 1 < 4) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        an[m][0] = tab[((s + 1) * 8 + 2 * m) * 64];
+                        an[m][1] = tab[((s + 1) * 8 + 2 * m + 1) * 64];
+                    }
+                }
+            }
+            u32x4 bh_n = bh_c, bl_n = bl_c;
+            if (idx + 1 < 4 * FE_NT) {
+                const int s1 = (idx + 1) / FE_NT, j1 = (idx + 1) - s1 * FE_NT;
+                if (j1 == 0) setup(s1, ks);
+                build(ks, j1, bh_n, bl_n);
+            }
+#define FMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) FMF(a[m][1], bh_c, acc[m][j]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) FMF(a[m][0], bl_c, acc[m][j]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) FMF(a[m][0], bh_c, acc[m][j]);
+#undef FMF
+            bh_c = bh_n;
+            bl_c = bl_n;
+        }
+    }
+
+    FE16_TS(3)
+    // ---- undo the scales; the (j = 0, j = 240) pair: Re X[k] += (-1)^k x[240] (h[240] = 1, h[0] = 0); square
+    f32x2 sq[4][FE_NT][2];
+#pragma unroll
+    for (int j = 0; j < FE_NT; ++j) {
+        const float c = w < 2 ? tsg * lds[fb + 244 + j * TILE_WORDS] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x2 x = __builtin_elementwise_fma((f32x2){acc[m][j][2 * hh], acc[m][j][2 * hh + 1]}, (f32x2){post, post}, (f32x2){c, c});
+                sq[m][j][hh] = x * x;
+            }
+    }
+    __syncthreads();  // every wave is done with the sample image
+
+    // ---- power tile P[bin][frame] = Re^2 + Im^2 (row stride PS words).  Each cell has one Re and one Im owner: in
+    //      the first half-phase the Re waves store their row tiles 0-1 and the Im waves their row tiles 2-3, in the
+    //      second each adds the other half into the cells its partner stored (a + b = b + a exactly; plain
+    //      read-add-write: ds_add_f32 was measured 8x slower).
+    const int kpar = w & 1;   // waves 0,2: even bins; 1,3: odd bins
+    float* pt = lds + (8 * g + kpar) * PS + fcol;
+#define P_PHASE(M0, OP)                                                                        \
+    _Pragma("unroll") for (int mm = 0; mm < 2; ++mm)                                           \
+    _Pragma("unroll") for (int j = 0; j < FE_NT; ++j)                                          \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+        float* cell = pt + (2 * (16 * ((M0) + mm) + r)) * PS + 16 * j;                         \
+        const float v = sq[(M0) + mm][j][r >> 1][r & 1];                                       \
+        OP;                                                                                    \
+    }
+    if (w < 2) { P_PHASE(0, *cell = v) } else { P_PHASE(2, *cell = v) }
+    __syncthreads();
+    if (w < 2) { P_PHASE(2, *cell += v) } else { P_PHASE(0, *cell += v) }
+#undef P_PHASE
+    __syncthreads();
+    issue(min(unit + (int)gridDim.x, nunits - 1), tid);   // the accumulators are dead: prefetch the next unit's samples
+
+    FE16_TS(4)
+    // ---- mel + log + "DCT of length 1" (x2).  Lane = frame (consecutive lanes read consecutive words of a bin's row:
+    //      no bank conflicts), waves 0-1 take the bands below mel_split, waves 2-3 the rest; weights are LDS broadcasts
+    //      of the packed non-zero taps.  Results go through a transposed LDS tile so that the stores are whole rows.
+    {
+        const int tl = tid & 127;
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+        const int f_lo = half ? p.mel_split : 0, f_hi = half ? p.n_mels : p.mel_split;
+        float* outt = lds + OUT_OFF;
+        if (tl < nfr) {
+            const float* pr = lds + tl;
+            // two bands per step (two independent FMA chains); the host pads both to the same number of groups of
+            // four taps; a padded tap has weight 0 and re-reads an existing row
+            for (int f = f_lo; f < f_hi; f += 2) {
+                const int f1 = min(f + 1, f_hi - 1);
+                const int lo0 = __builtin_amdgcn_readfirstlane(band[2 * f]);
+                const int off0 = __builtin_amdgcn_readfirstlane(band[2 * f + 1]);
+                const int ng = (__builtin_amdgcn_readfirstlane(band[2 * f + 3]) - off0) >> 2;
+                const int lo1 = __builtin_amdgcn_readfirstlane(band[2 * f1]);
+                const int off1 = __builtin_amdgcn_readfirstlane(band[2 * f1 + 1]);
+                const f32x4* wt0 = reinterpret_cast<const f32x4*>(taps + off0);
+                const f32x4* wt1 = reinterpret_cast<const f32x4*>(taps + off1);
+                float v0 = 0.f, v1 = 0.f;
+#define MEL_BODY(NG)                                                                                  \
+    {                                                                                                 \
+        f32x4 wq0[NG], wq1[NG];                                                                       \
+        float x0[4 * NG], x1[4 * NG];                                                                 \
+        _Pragma("unroll") for (int q = 0; q < NG; ++q) {                                              \
+            wq0[q] = wt0[q];                                                                          \
+            wq1[q] = wt1[q];                                                                          \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4 * NG; ++i) {                                          \
+            x0[i] = pr[min(lo0 + i, P_ROWS - 1) * PS];                                                \
+            x1[i] = pr[min(lo1 + i, P_ROWS - 1) * PS];                                                \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4 * NG; ++i) {                                          \
+            v0 = fmaf(wq0[i >> 2][i & 3], x0[i], v0);                                                 \
+            v1 = fmaf(wq1[i >> 2][i & 3], x1[i], v1);                                                 \
+        }                                                                                             \
+    }
+                if (ng <= 1) MEL_BODY(1) else if (ng == 2) MEL_BODY(2) else if (ng == 3) MEL_BODY(3) else MEL_BODY(4)
+#undef MEL_BODY
+                outt[tl * OUT_STRIDE + f] = v0;
+                outt[tl * OUT_STRIDE + f1] = v1;
+            }
+        }
+    }
+    FE16_TS(5)
+    __syncthreads();
+    FE16_TS(6)
+    // ---- log and x2 ("DCT of length 1") on the way out.  The values are read and finished into registers first; then
+    //      (after a barrier) the next unit's samples go into the image region, and only then are the rows stored:
+    //      waiting for the prefetched samples must not wait for this unit's stores (one counter covers both).
+    constexpr int COPY_IT = (FE_FRAMES * FE16_MAX_MELS + 255) / 256;
+    float outv[COPY_IT];
+    const int nout = nfr * p.n_mels;
+    {
+        const float* outt = lds + OUT_OFF;
+        const int dq = 256 / p.n_mels, dr = 256 - dq * p.n_mels;
+        int tl = tid / p.n_mels, f = tid - tl * p.n_mels;
+#pragma unroll
+        for (int it = 0; it < COPY_IT; ++it) {      // straight-line: elements past the end re-read the tile's last word
+            const float v = outt[min(tl * OUT_STRIDE + f, FE_FRAMES * OUT_STRIDE - 1)];
+            float lg = v >= 1e-30f ? __logf(v) : v;
+            if (__builtin_expect(v > 0.f && v < 1e-30f, 0)) lg = logf(v);      // subnormal-range powers: the slow exact path
+            outv[it] = 2.0f * lg;
+            f += dr;
+            tl += dq;
+            if (f >= p.n_mels) {
+                f -= p.n_mels;
+                ++tl;
+            }
+        }
+    }
+    FE16_TS(7)
+    __syncthreads();   // the output tile and the power tile are dead: the next unit's samples may overwrite them
+    if (unit + (int)gridDim.x < nunits) stage(unit + gridDim.x, tid);
+    {
+        float* dst = p.feat + ((size_t)clip * p.T + t0) * p.n_mels;
+#pragma unroll
+        for (int it = 0; it < COPY_IT; ++it)
+            if (it * 256 + tid < nout) dst[it * 256 + tid] = outv[it];
+    }
+#ifdef FE16_TIMING
+    if (lane == 0) {
+        const unsigned long long t8 = __builtin_readcyclecounter();
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.feat + ((size_t)clip * p.T + t0) * p.n_mels + 40 * (1 + w * 10));
+        for (int i = 0; i < 8; ++i) o[i] = ts[i];
+        o[8] = t8;
+    }
+#endif
+    }
+}
+
+size_t frontend_f16_lds_bytes() {
+    static_assert(FE_ROWS * PS <= IMG_WORDS, "power tile must fit the image region");
+    const size_t words = (size_t)IMG_WORDS + CONST_WORDS + 4;
+    return ((words * sizeof(float)) + 15) & ~(size_t)15;
+}
+
+hipError_t launch_frontend_f16(const FrontendParams& p, int n_cu, hipStream_t s) {
+    static bool attr_done = false;
+    const size_t lds = frontend_f16_lds_bytes();
+    if (!attr_done) {
+        for (const void* k : {(const void*)frontend_f16_kernel<0>, (const void*)frontend_f16_kernel<1>, (const void*)frontend_f16_kernel<2>}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        attr_done = true;
+    }
+    if (p.B <= 0) return hipSuccess;
+    const long long units = (long long)p.B * p.chunks;
+    const dim3 grid((unsigned)std::min<long long>(units, 2LL * n_cu));      // persistent: two workgroups per CU
+    if (p.wav) hipLaunchKernelGGL(frontend_f16_kernel<0>, grid, dim3(256), lds, s, p);
+    else if (!p.noise) hipLaunchKernelGGL(frontend_f16_kernel<1>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(frontend_f16_kernel<2>, grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+// A fragments: [GEMM w][k-step][row tile][part][lane] x 4 words (k-slots 8g .. 8g+7 of row 16m + (lane & 15));
+// hann2 = h[j] (128), h[240-j] (128)
+void build_dft_table_f16(std::vector<unsigned>& tab, std::vector<float>& hann2) {
+    tab.assign((size_t)4 * 4 * 4 * 2 * 64 * 4, 0u);
+    hann2.assign(HW_WORDS, 0.f);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int w = 0; w < 4; ++w)
+        for (int s = 0; s < 4; ++s)
+            for (int m = 0; m < 4; ++m)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = 2 * (16 * m + (lane & 15)) + (w & 1);
+                        const int j = 32 * s + 8 * (lane >> 4) + e;
+                        double v = 0.0;
+                        if (j >= 1 && j <= 120) {
+                            const int ph = (int)(((long long)k * j) % FE_NFFT);   // exact angle reduction
+                            const double ang = two_pi * ph / FE_NFFT;
+                            v = (w < 2 ? std::cos(ang) : std::sin(ang)) * (j == 120 ? 0.5 : 1.0) * A_SCALE;
+                        }
+                        const float vf = (float)v;
+                        const unsigned short h = f16_rne_host(vf);
+                        const unsigned short l = f16_rne_host(vf - f16_to_f_host(h));
+                        const size_t base = (((((size_t)w * 4 + s) * 4 + m) * 2) * 64 + lane) * 4 + (e >> 1);
+                        tab[base] |= (unsigned)h << (16 * (e & 1));
+                        tab[base + 64 * 4] |= (unsigned)l << (16 * (e & 1));
+                    }
+    for (int j = 0; j < 128; ++j) {
+        hann2[j] = (float)(0.5 - 0.5 * std::cos(two_pi * j / FE_NFFT));
+        hann2[128 + j] = (float)(0.5 - 0.5 * std::cos(two_pi * (240 - j) / FE_NFFT));
+    }
+}
+
+}  // namespace kws

@@ -82,8 +82,9 @@ struct kws_handle {
     LwMode lw_mode = LW_TILED;
 
     // front end
-    DevMem dft, hann, melw, mel_lo, mel_hi, edge_hann, edge_trig;
-    int mel_maxw = 0;
+    DevMem dft, hann, dft16, consts16, melw, mel_lo, mel_hi, edge_hann, edge_trig;
+    bool fe_fp32 = false;                  // KWS_FRONTEND_IMPL=fp32: the fp32-input MFMA front end (frontend.hip)
+    int mel_maxw = 0, mel_ntaps = 0, mel_split = 0, mel_maxbin = 0;
 
     // parameters
     std::set<std::string> required, loaded;
@@ -175,6 +176,50 @@ int setup_frontend(kws_handle* h) {
     int rc;
     if ((rc = h->dft.upload(tab.data(), tab.size() * sizeof(float)))) return rc;
     if ((rc = h->hann.upload(hann.data(), hann.size() * sizeof(float)))) return rc;
+    std::vector<unsigned> tab16;
+    std::vector<float> hann2;
+    build_dft_table_f16(tab16, hann2);
+    if ((rc = h->dft16.upload(tab16.data(), tab16.size() * sizeof(unsigned)))) return rc;
+    // constants of the fp16 front end, one blob: window; non-zero mel taps band after band; (first bin, tap offset)
+    // per band.  Its mel stage gives waves 0-1 the bands below mel_split and waves 2-3 the rest, two bands per step:
+    // split where the estimated cost (a fixed part per step + its groups of four taps) is halved, pad the two bands
+    // of a step to the same number of groups.
+    std::vector<int> ng(d.n_mels);
+    int cost_all = 0;
+    for (int i = 0; i < d.n_mels; ++i) {
+        ng[i] = std::max(1, (hi[i] - lo[i] + 3) / 4);
+        cost_all += 4 + ng[i];
+        h->mel_maxbin = std::max(h->mel_maxbin, hi[i]);
+    }
+    h->mel_split = d.n_mels;
+    for (int i = 0, c = 0; i < d.n_mels; ++i) {
+        if (2 * c >= cost_all) {
+            h->mel_split = i;
+            break;
+        }
+        c += 4 + ng[i];
+    }
+    for (int half = 0; half < 2; ++half) {
+        const int f0 = half ? h->mel_split : 0, f1 = half ? d.n_mels : h->mel_split;
+        for (int f = f0; f + 1 < f1; f += 2) ng[f] = ng[f + 1] = std::max(ng[f], ng[f + 1]);
+    }
+    std::vector<float> blob(FE16_CONST_WORDS, 0.f);
+    std::copy(hann2.begin(), hann2.end(), blob.begin());
+    int* bandtab = reinterpret_cast<int*>(blob.data() + 256 + FE16_MAX_TAPS);
+    int ntaps = 0;
+    for (int i = 0; i < d.n_mels && d.n_mels <= FE16_MAX_MELS; ++i) {
+        bandtab[2 * i] = lo[i];
+        bandtab[2 * i + 1] = ntaps;
+        for (int k = lo[i]; k < hi[i] && ntaps + (k - lo[i]) < FE16_MAX_TAPS; ++k)
+            blob[256 + ntaps + (k - lo[i])] = wts[(size_t)i * FE_ROWS + k];
+        ntaps += 4 * ng[i];
+        bandtab[2 * i + 3] = ntaps;       // the next band's offset (end marker after the last band)
+    }
+    h->mel_ntaps = ntaps;
+    if ((rc = h->consts16.upload(blob.data(), blob.size() * sizeof(float)))) return rc;
+    const char* fimpl = std::getenv("KWS_FRONTEND_IMPL");
+    h->fe_fp32 = (fimpl && std::strcmp(fimpl, "fp32") == 0) || h->mel_ntaps > FE16_MAX_TAPS || d.n_mels > FE16_MAX_MELS || h->mel_maxw > 16 ||
+                 h->mel_maxbin > FE16_MAX_BIN;   // filterbanks the fp16 kernel's LDS tables cannot hold
     std::vector<float> ehann, etrig;
     build_edge_tables(ehann, etrig);
     if ((rc = h->edge_hann.upload(ehann.data(), ehann.size() * sizeof(float)))) return rc;
@@ -920,8 +965,13 @@ static int mfcc_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, con
     if ((rc = prof_mark(h, h->ev_front, s))) return rc;
     FrontendParams p{d_wav, reinterpret_cast<const short*>(d_pcm), d_noise, noise_pct, d_feat, h->dft.as<f32x4>(),
                      h->hann.as<float>(), h->melw.as<float>(), h->mel_lo.as<int>(), h->mel_hi.as<int>(), B, n_samples, T,
-                     h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, h->mel_maxw, clip_stride < 0 ? n_samples : clip_stride};
-    HIP_TRY(launch_frontend(p, s));
+                     h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, h->mel_maxw, clip_stride < 0 ? n_samples : clip_stride,
+                     h->dft16.as<void>(), h->consts16.as<float>(), h->mel_split};
+    // the fp16 kernel reads whole 16-byte groups: rows (and base pointers) that are not 16-byte aligned -- odd clip
+    // lengths, sliced buffers -- take the fp32-input kernel, which stages element-wise
+    const bool aligned = (p.clip_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(d_wav) | reinterpret_cast<uintptr_t>(d_noise)) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(d_pcm) & 7) == 0;
+    HIP_TRY(h->fe_fp32 || !aligned ? launch_frontend(p, s) : launch_frontend_f16(p, h->n_cu, s));
     return prof_mark(h, h->ev_front, s);
 }
 

@@ -86,7 +86,12 @@ struct FrontendParams {
     int B, n_samples, T, n_mels, chunks;
     int mel_maxw;         // widest mel filter in bins (fast path keeps <= 16 weights in registers)
     long long clip_stride;   // samples between the starts of consecutive clips (n_samples for a packed batch)
+    const void* dft16;    // fp16 two-part cos/sin fragments (frontend_f16x3.hip)
+    const float* consts16;   // FE16_CONST_WORDS: h[j] (128), h[240-j] (128); mel taps; (first bin, tap offset) per band
+    int mel_split;           // first band of the upper half of the mel work
 };
+constexpr int FE16_MAX_TAPS = 768, FE16_MAX_MELS = 40, FE16_MAX_BIN = 120;   // what frontend_f16_kernel's LDS tables hold
+constexpr int FE16_CONST_WORDS = 256 + FE16_MAX_TAPS + 2 * FE16_MAX_MELS + 4;
 // streaming windows whose shift is a multiple of the hop: edge frames + copy of the shared rows (frontend.hip)
 struct WindowEdgeParams {
     const float* stream;        // the long waveform; window i starts at sample i * shift
@@ -104,6 +109,8 @@ void build_edge_tables(std::vector<float>& hann, std::vector<float>& trig);
 size_t frontend_lds_bytes(int T);
 hipError_t launch_frontend(const FrontendParams& p, hipStream_t s);
 void build_dft_table(std::vector<float>& dft, std::vector<float>& hann);  // host side, double precision trig
+hipError_t launch_frontend_f16(const FrontendParams& p, int n_cu, hipStream_t s);     // frontend_f16x3.hip (default)
+void build_dft_table_f16(std::vector<unsigned>& tab, std::vector<float>& hann2);
 
 // ---------------------------------------------------------------- fused res8 (res8_fused.hip)
 constexpr int R8_C = 45, R8_H = 25, W8_W = 13, R8_NPOS = 325;
