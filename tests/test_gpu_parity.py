@@ -79,6 +79,36 @@ def test_frontend_reference_signature_and_odd_lengths(torch_cuda):
         assert err.max() < 1e-2, n                          # dithered tone: bands ~57 dB down sit at the fp32 floor
 
 
+def test_frontend_kernels_agree_and_scale_with_loud_input(torch_cuda, monkeypatch):
+    """Two independent front-end kernels: the default computes the DFT with three-term fp16 products (samples scaled by
+    a per-chunk power of two), KWS_FRONTEND_IMPL=fp32 with the fp32-input MFMA.  Both must sit equally close to the
+    float64 restatement on well-conditioned clips; scaling the samples by 2^k (up to the int16 range, far past what
+    fp16 holds unscaled) must move every feature 2 ln(mel power) by 2 ln(4^k) = 4 k ln 2."""
+    torch = torch_cuda
+    from honk2_amd.utils import AudioProcessor
+    from oracle import frontend, weights
+    wav = weights.make_waveforms(12, seed=77)
+    noise_like = [b for b in range(12) if b % 12 not in (0, 1)]           # skip the all-zero clip and the bare tone
+    want = frontend.compute_mfccs_batch(wav, "f64")
+    x = torch.from_numpy(wav).cuda()
+    f16 = AudioProcessor().compute_mfccs_batch(x).cpu().numpy()
+    monkeypatch.setenv("KWS_FRONTEND_IMPL", "fp32")
+    f32 = AudioProcessor().compute_mfccs_batch(x).cpu().numpy()
+    monkeypatch.delenv("KWS_FRONTEND_IMPL")
+    e16 = np.abs(f16 - want)[noise_like].max()
+    e32 = np.abs(f32 - want)[noise_like].max()
+    assert e16 < 1e-3 and e32 < 1e-3, (e16, e32)
+    assert e16 <= 2.0 * e32 + 1e-6, (e16, e32)                            # not a reduced-precision mode
+    assert np.abs(f16 - f32)[noise_like].max() < 1e-3
+    assert np.array_equal(f16[0], np.zeros_like(f16[0]))                 # silence stays exactly zero
+    ap = AudioProcessor()
+    base = ap.compute_mfccs_batch(x[noise_like]).cpu().numpy()
+    for k in (3, 15):                                                     # |x| up to 8 and up to 32768
+        loud = ap.compute_mfccs_batch(x[noise_like] * float(2 ** k)).cpu().numpy()
+        assert np.isfinite(loud).all()
+        assert np.abs(loud - (base + 4.0 * k * np.log(2.0))).max() < 2e-4, k
+
+
 # ------------------------------------------------------------------ models against the reference goldens
 @pytest.mark.parametrize("fname", golden_model_files())
 def test_model_logits_match_reference(torch_cuda, fname):
