@@ -34,9 +34,14 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int CELL_B = 192;                           // bytes per map cell: 2 parts x 48 channels x 2
-constexpr int PART_B = 96;
-constexpr int MAP_BYTES = 384 * CELL_B;               // 73 728
+// part-major map: [2 parts][384 cells][48 channels] fp16.  A cell is 96 B = 6 slots of 16 B, so eight consecutive cells
+// start in eight different even (or odd) slots of the 16 a bank row has, and the two k-groups a ds_read_b128 lane
+// group mixes read channel blocks of opposite parity: B-fragment reads conflict only where a position tile wraps to
+// the next map row (cell-major [cell][part][channel], 192-B cells: 2.8x the conflict-free LDS cycles on reads, 8x on
+// the epilogue's 8-byte stores; this layout 2.0x / 4.6x, model in DESIGN.md section 4.2)
+constexpr int CELL_B = 96;                            // bytes per map cell and part: 48 channels x 2
+constexpr int PART_B = 384 * CELL_B;                  // 36 864
+constexpr int MAP_BYTES = 2 * PART_B;                 // 73 728
 constexpr int FS = 41;                                // staged feature row stride (fp32 words)
 constexpr int FEAT_BYTES = ((102 * FS * 4 + 15) / 16) * 16;
 static_assert(FEAT_BYTES <= MAP_BYTES, "the feature map is staged inside the (idle) activation map");
