@@ -176,14 +176,14 @@ def main():
         # HBM bytes per launch cannot be measured from inside the process; when the committed counter summary of this very
         # workload (same kernel, same clips per launch) is present, quote it: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate passes, KB units, x2 correction on the gfx950 fetch counter (MI355X_MICROARCH.md).
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "v7_summary.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "v8_summary.json")
         if plan == "res8_fused" and nloc == 65536 and os.path.exists(pmc):
             try:
                 with open(pmc) as f:
                     summ = json.load(f)
                 ent = next(v for k, v in summ.items() if "res8h_kernel" in k)
                 roofline["traffic"] = (2.0 * ent["FETCH_SIZE"] + ent["WRITE_SIZE"]) * 1024.0
-                roofline["traffic_source"] = "profiles/r01/v7_summary.json (rocprofv3 --pmc, same command)"
+                roofline["traffic_source"] = "profiles/r01/v8_summary.json (rocprofv3 --pmc, same command)"
             except Exception:
                 pass
         out = {
