@@ -189,7 +189,7 @@ def main():
         out = {
             "metric": "1s-clips/sec end-to-end (wav->logits), res8 GSCv2", "value": clips_per_s, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": ("f32 (f16x3: fp32-accurate 3-term fp16 products, fp32 accumulate; fp32 front end)" if plan == "res8_fused" else "f32 (bf16x6: fp32-accurate 6-term bf16 products, fp32 accumulate; fp32 front end)" if plan == "res8_fused_bf16x6" else "f32"), "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": ("f32 (f16x3: fp32-accurate 3-term fp16 products, fp32 accumulate, in the conv stack and in the front end's DFT)" if plan == "res8_fused" else "f32 (bf16x6: fp32-accurate 6-term bf16 products, fp32 accumulate; fp32 front end)" if plan == "res8_fused_bf16x6" else "f32"), "data": "synthetic",
             "config": {"workload": f"res8 fp32 wav->logits, global batch {args.batch} one-second 16 kHz clips "
                                    f"(BASELINE configs[3]), {nloc} clips/GPU, random-init weights",
                        "global_batch": args.batch, "clips_per_gpu": nloc, "n_samples": 16000,
