@@ -314,6 +314,15 @@ size_t res8h_lds_bytes() { return (size_t)X_LDS_BYTES; }
 // VGPR-accumulator MFMAs, which one wave can only issue at half rate (tools/mfma_dep_probe.cpp): alone in its k-loop a
 // workgroup does not fill the pipe.  Forcing AGPR accumulators splits the budget 128 / 128 and spills (18.2 ms); a
 // start-up stagger of the second workgroup changes nothing.
+// phase timestamps for tools/r8_phases.py: build with -DR8H_TIMING (they overwrite the consumed feature rows)
+#ifdef R8H_TIMING
+#define R8H_TS_DECL unsigned long long ts[8];
+#define R8H_TS(i) ts[i] = __builtin_readcyclecounter();
+#else
+#define R8H_TS_DECL
+#define R8H_TS(i)
+#endif
+
 template <int TERMS>   // 3: fp32-accurate; 1: plain fp16 operands (KWS_DTYPE_F16)
 __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
@@ -333,6 +342,8 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 
     for (int clip = blockIdx.x; clip < p.B; clip += gridDim.x) {
         __syncthreads();  // previous clip's tail has consumed red/mvec and the map
+        R8H_TS_DECL
+        R8H_TS(0)
 
         // Everything derived from the lane id is recomputed per clip from an opaque copy of it.  Otherwise the compiler
         // hoists some 80 per-lane addresses and selectors out of this loop, keeps them alive across it and -- at 256
@@ -383,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
             if (tid < 101) feat_w[(tid + 1) * FS] = 0u;
         }
         __syncthreads();
+        R8H_TS(1)
 
         // ---- conv_0 + ReLU + AvgPool(4,3) on the fp16 matrix cores, result in accumulator layout = prev_x.
         //      K = 9 taps sit in k-slots 0..8 of one 16x16x32 step: lane group 0 supplies taps 0..7, group 1 tap 8, the rest
@@ -476,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
             }
 #undef C0_FRAG
         }
+        R8H_TS(2)
         // every wave is done with the staged features: turn the region back into an all-zero map (halo cells included), then
         // write the pooled conv_0 output into its interior
         int shift;   // range guard of the map the next layer reads
@@ -505,12 +518,23 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         }
         __syncthreads();
 
+        R8H_TS(3)
         x_layer<TERMS, false, false>(p, c, 0, clip, prev, prevx, shift);
+        R8H_TS(4)
         x_layer<TERMS, true, false>(p, c, 1, clip, prev, prevx, shift);
+        R8H_TS(5)
         x_layer<TERMS, false, false>(p, c, 2, clip, prev, prevx, shift);
         x_layer<TERMS, true, false>(p, c, 3, clip, prev, prevx, shift);
         x_layer<TERMS, false, false>(p, c, 4, clip, prev, prevx, shift);
+        R8H_TS(6)
         x_layer<TERMS, true, true>(p, c, 5, clip, prev, prevx, shift);
+        R8H_TS(7)
+#ifdef R8H_TIMING
+        if ((threadIdx.x & 63) == 0) {      // the clip's features are dead: park the timestamps there (tools/r8_phases.py)
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.feat) + (size_t)clip * p.T * p.F) + 8 * w;
+            for (int i = 0; i < 8; ++i) o[i] = ts[i];
+        }
+#endif
     }
 }
 
