@@ -79,6 +79,25 @@ def test_frontend_reference_signature_and_odd_lengths(torch_cuda):
         assert err.max() < 1e-2, n                          # dithered tone: bands ~57 dB down sit at the fp32 floor
 
 
+def test_frontend_chunk_and_edge_geometry(torch_cuda):
+    """16-byte-aligned lengths around the fp16 kernel's edge cases: barely longer than the reflect padding, one frame
+    into a second 112-frame chunk, exactly 112 frames, and PCM input for the same lengths."""
+    torch = torch_cuda
+    from honk2_amd.utils import AudioProcessor
+    from oracle import frontend, weights
+    ap = AudioProcessor()
+    for n in (244, 320, 1600, 160 * 111, 160 * 111 + 156, 160 * 112, 160 * 112 + 4, 160 * 224 + 8):
+        wav = weights.make_waveforms(4, n_samples=n, seed=n)[2:]          # two white-noise clips
+        want = frontend.compute_mfccs_batch(wav, "f64")
+        got = ap.compute_mfccs_batch(torch.from_numpy(wav).cuda()).cpu().numpy()
+        assert got.shape == want.shape == (2, 1 + n // 160, 40), n
+        assert np.abs(got - want).max() < 1e-3, (n, np.abs(got - want).max())
+        pcm = np.round(wav * 32767.0).astype(np.int16)
+        want16 = frontend.compute_mfccs_batch(pcm.astype(np.float32) / np.float32(32768.0), "f64")
+        got16 = ap.compute_mfccs_batch(torch.from_numpy(pcm).cuda()).cpu().numpy()
+        assert np.abs(got16 - want16).max() < 1e-3, (n, np.abs(got16 - want16).max())
+
+
 def test_frontend_kernels_agree_and_scale_with_loud_input(torch_cuda, monkeypatch):
     """Two independent front-end kernels: the default computes the DFT with three-term fp16 products (samples scaled by
     a per-chunk power of two), KWS_FRONTEND_IMPL=fp32 with the fp32-input MFMA.  Both must sit equally close to the
