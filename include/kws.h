@@ -31,6 +31,9 @@
  *     from split fp32 operands: three exact fp16 x fp16 terms of two-part fp16 splits (weights pre-scaled by a power of two per
  *     layer; error <= 3 * 2^-22 |ab|, measured as close to a float64 evaluation as an fp32 implementation; activations must
  *     stay below 65504 in magnitude), or -- KWS_RES8_IMPL=bf16x6 -- six bf16 x bf16 terms of three-part bf16 splits.
+ *     The front end's DFT uses the same three-term fp16 products with the samples scaled by a power of two per clip chunk
+ *     (any finite sample magnitude is fine); KWS_FRONTEND_IMPL=fp32 selects its fp32-input matrix-core form, which also
+ *     serves waveform rows that are not 16-byte aligned.
  */
 #ifndef KWS_H_
 #define KWS_H_
