@@ -299,12 +299,13 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
             const f32x2 b = __builtin_elementwise_fma((f32x2){k.hj[e], k.hj[e + 1]}, u, q);
             const f16x2 h = {(_Float16)b[0], (_Float16)b[1]};
             const unsigned hp = __builtin_bit_cast(unsigned, h);
-            float r0, r1;   // b - h, the fp16 operand read straight from its half of the packed register
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(b[0]));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(b[1]));
-            const f16x2 l = {(_Float16)r0, (_Float16)r1};
+            // l = fp16(b - h): the mixed-precision FMA reads h from its half of the packed register and writes the
+            // rounded fp16 result into the low / high half of the destination
+            unsigned lp;
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(b[0]));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(b[1]));
             bh[e >> 1] = hp;
-            bl[e >> 1] = __builtin_bit_cast(unsigned, l);
+            bl[e >> 1] = lp;
         }
     };
     {
