@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
             for (int e = 0; e < 4; ++e) eraw[e][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * ex[e], 0, 0);
         } else {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(p.pcm + cbase), 0, n * 2, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((MODE == 2 ? p.noise : p.wav) + cbase), 0, n * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rz =       // only MODE 2 reads through it
+                __builtin_amdgcn_make_buffer_rsrc(MODE == 2 ? const_cast<float*>(p.noise + cbase) : nullptr, 0, MODE == 2 ? n * 4 : 0, 0x00020000);
 #pragma unroll
             for (int it = 0; it < iters; ++it) {
                 const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, 2 * g0 + 1920 * it, 0, 0));
