@@ -347,11 +347,10 @@ static hipError_t launch_t3k(const TileConvParams& p, hipStream_t s) {
     const unsigned grid = (unsigned)((p.total + tile - 1) / tile);
     const size_t lds = conv3x3_tile_lds_bytes(NB * 8, p.Ws, F16);
     auto k = conv3x3_tile_kernel<NB, MT, TERMS, F16>;
-    static bool attr_done = false;   // per instantiation: allow > 64 KB of dynamic LDS
-    if (!attr_done) {
+    static DeviceOnce attr_once;   // per instantiation: allow > 64 KB of dynamic LDS
+    if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
     return hipGetLastError();

@@ -239,13 +239,12 @@ size_t frontend_lds_bytes(int) {
 }
 
 hipError_t launch_frontend(const FrontendParams& p, hipStream_t s) {
-    static bool attr_done = false;
+    static DeviceOnce attr_once;
     const size_t lds = frontend_lds_bytes(p.T);
-    if (!attr_done) {
+    if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute((const void*)frontend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     if (p.B <= 0) return hipSuccess;
     hipLaunchKernelGGL(frontend_kernel, dim3((unsigned)(p.B * p.chunks)), dim3(256), lds, s, p);

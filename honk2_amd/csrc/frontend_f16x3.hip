@@ -489,14 +489,13 @@ size_t frontend_f16_lds_bytes() {
 }
 
 hipError_t launch_frontend_f16(const FrontendParams& p, int n_cu, hipStream_t s) {
-    static bool attr_done = false;
+    static DeviceOnce attr_once;
     const size_t lds = frontend_f16_lds_bytes();
-    if (!attr_done) {
+    if (attr_once.first()) {
         for (const void* k : {(const void*)frontend_f16_kernel<0>, (const void*)frontend_f16_kernel<1>, (const void*)frontend_f16_kernel<2>}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        attr_done = true;
     }
     if (p.B <= 0) return hipSuccess;
     const long long units = (long long)p.B * p.chunks;

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,6 +58,18 @@ inline float weight_scale_pow2(const float* w, size_t n) {
     std::frexp(mx, &ex);                 // mx = f * 2^ex, f in [0.5, 1)
     return std::ldexp(1.f, 8 - ex);
 }
+
+// `static DeviceOnce once;  if (once.first()) { hipFuncSetAttribute(...) }`: true the first time it is asked on the
+// current HIP device (function attributes such as the dynamic-LDS limit are per device; a process may drive several)
+struct DeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+        const unsigned long long bit = 1ull << dev;
+        return (done.fetch_or(bit) & bit) == 0;
+    }
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

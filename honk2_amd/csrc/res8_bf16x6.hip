@@ -419,8 +419,8 @@ __global__ __launch_bounds__(256, 1) void res8x_kernel(Res8xParams p) {
 }
 
 hipError_t launch_res8x(const Res8xParams& p, int grid, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute((const void*)res8x_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)res8x_lds_bytes());
         if (e != hipSuccess) return e;
@@ -430,7 +430,6 @@ hipError_t launch_res8x(const Res8xParams& p, int grid, hipStream_t s) {
         e = hipFuncSetAttribute((const void*)res8x_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)res8x_lds_bytes());
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     if (p.B <= 0) return hipSuccess;
     if (p.terms == 1)

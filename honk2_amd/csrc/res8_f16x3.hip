@@ -539,14 +539,13 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 }
 
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute((const void*)res8h_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)res8h_lds_bytes());
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)res8h_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res8h_lds_bytes());
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     if (p.B <= 0) return hipSuccess;
     if (p.terms == 1)

@@ -361,11 +361,10 @@ __global__ __launch_bounds__(256, 2) void res8_kernel(Res8Params p) {
 }
 
 hipError_t launch_res8(const Res8Params& p, int grid, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute((const void*)res8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     if (p.B <= 0) return hipSuccess;
     // p.debug bit 2 (timing experiments only): pad LDS so that only one workgroup fits a CU
