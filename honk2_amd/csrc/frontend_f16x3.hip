@@ -35,16 +35,28 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XS = 164;                                        // LDS words per hop: 160 samples + 4
-constexpr int X_LEN = 160 * (FE_FRAMES - 1) + FE_NFFT;         // staged samples: 114 hop blocks
+// FE16_NT = 4 (64-frame units, 48 KB of LDS, 168 registers: three workgroups per CU) was measured: 3.79 ms against 3.26 ms
+// for 65 536 clips -- 8 tiles of work per clip instead of 7, twice the A-fragment traffic, per-unit costs paid twice.
+#ifndef FE16_NT
+#define FE16_NT 7
+#endif
+constexpr int NTT = FE16_NT;                                   // 16-frame tiles per unit
+constexpr int FRM = 16 * NTT;                                  // frames per unit
+constexpr int WG_PER_CU = NTT <= 4 ? 3 : 2;
+constexpr int SLOTS = FRM <= 64 ? 64 : 128;                    // mel stage: lanes per frame slot group
+constexpr int MEL_PARTS = 256 / SLOTS;                         // band ranges worked on in parallel
+constexpr int X_LEN = 160 * (FRM - 1) + FE_NFFT;               // staged samples: FRM + 2 hop blocks
 constexpr int X_WORDS = X_LEN + 4 * ((X_LEN + 159) / 160);
 constexpr int TILE_WORDS = 16 * XS;                            // LDS words between consecutive 16-frame tiles
 constexpr int HW_WORDS = 256;                                  // h[j], h[240-j] for j = 0..127
 constexpr float A_SCALE = 128.f;
-constexpr int PS = 118;                                        // row stride (words) of the power tile P[bin][frame]
+constexpr int PS = FRM + 6 - (FRM % 4);                        // row stride (words) of the power tile P[bin][frame]: = 2 mod 4
+static_assert(PS % 4 == 2 && PS >= FRM, "rows of lane groups 0 and 1 must start 16 banks apart");
 constexpr int P_ROWS = 120;                                    // bins the mel stage may read (FE16_MAX_BIN)
 constexpr int OUT_STRIDE = 41;                                 // transposed output tile [frame][band]
 constexpr int OUT_OFF = P_ROWS * PS;
-constexpr int IMG_WORDS = X_WORDS > OUT_OFF + FE_FRAMES * OUT_STRIDE ? X_WORDS : OUT_OFF + FE_FRAMES * OUT_STRIDE;
+constexpr int IMG_WORDS0 = X_WORDS > OUT_OFF + FRM * OUT_STRIDE ? X_WORDS : OUT_OFF + FRM * OUT_STRIDE;
+constexpr int IMG_WORDS = IMG_WORDS0 > FE_ROWS * PS ? IMG_WORDS0 : FE_ROWS * PS;
 constexpr int CONST_WORDS = FE16_CONST_WORDS;
 }  // namespace
 
@@ -61,7 +73,7 @@ __device__ __forceinline__ int fx_idx(int i) { return i + 4 * (i / 160); }
 
 // MODE: 0 = fp32 samples, 1 = 16-bit PCM, 2 = PCM + additive noise clip
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) {
+__global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* hw = lds + IMG_WORDS;                                     // [window 256][mel taps][band table]: FE16_CONST_WORDS
     float* taps = hw + HW_WORDS;
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
     };
     auto issue = [&](int unit, int tid) {
         const int clip = unit / p.chunks;
-        const int t0 = (unit - clip * p.chunks) * FE_FRAMES;
+        const int t0 = (unit - clip * p.chunks) * FRM;
         const int org = 160 * t0 - FE_NFFT / 2;
         const size_t cbase = (size_t)clip * p.clip_stride;
         const int bs = tid / 40;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
         const int lane = tid & 63;
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int clip = unit / p.chunks;
-        const int t0 = (unit - clip * p.chunks) * FE_FRAMES;
+        const int t0 = (unit - clip * p.chunks) * FRM;
         const int org = 160 * t0 - FE_NFFT / 2;
         const int bs = tid / 40;
         const int off = tid - 40 * bs;
@@ -218,8 +230,8 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
     const int pcol = lane & 15;
     const int clip = unit / p.chunks;
     const int chunk = unit - clip * p.chunks;
-    const int t0 = chunk * FE_FRAMES;
-    const int nfr = min(FE_FRAMES, p.T - t0);
+    const int t0 = chunk * FRM;
+    const int nfr = min(FRM, p.T - t0);
     FE16_TS_DECL
     FE16_TS(0)
 
@@ -242,11 +254,11 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
     const float b_scale = __builtin_bit_cast(float, (unsigned)(127 + 13 - ex) << 23);
     const float post = __builtin_bit_cast(float, (unsigned)(127 - 20 + ex) << 23);   // 1 / (b_scale * A_SCALE)
 
-    f32x4 acc[4][FE_NT];
+    f32x4 acc[4][NTT];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int j = 0; j < FE_NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NTT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const float sgn = w >= 2 ? -1.f : 1.f;                   // s: Re rows use sums, Im rows differences
     const float tsg = (w == 1 || w == 2) ? -1.f : 1.f;       // t: sign of the (240-j) half
@@ -316,8 +328,8 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
         build(ks, 0, bh_c, bl_c);
         u32x4 a[4][2];
 #pragma unroll
-        for (int idx = 0; idx < 4 * FE_NT; ++idx) {
-            const int s = idx / FE_NT, j = idx - s * FE_NT;
+        for (int idx = 0; idx < 4 * NTT; ++idx) {
+            const int s = idx / NTT, j = idx - s * NTT;
             if (j == 0) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -333,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
                 }
             }
             u32x4 bh_n = bh_c, bl_n = bl_c;
-            if (idx + 1 < 4 * FE_NT) {
-                const int s1 = (idx + 1) / FE_NT, j1 = (idx + 1) - s1 * FE_NT;
+            if (idx + 1 < 4 * NTT) {
+                const int s1 = (idx + 1) / NTT, j1 = (idx + 1) - s1 * NTT;
                 if (j1 == 0) setup(s1, ks);
                 build(ks, j1, bh_n, bl_n);
             }
@@ -353,9 +365,9 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
 
     FE16_TS(3)
     // ---- undo the scales; the (j = 0, j = 240) pair: Re X[k] += (-1)^k x[240] (h[240] = 1, h[0] = 0); square
-    f32x2 sq[4][FE_NT][2];
+    f32x2 sq[4][NTT][2];
 #pragma unroll
-    for (int j = 0; j < FE_NT; ++j) {
+    for (int j = 0; j < NTT; ++j) {
         const float c = w < 2 ? tsg * lds[fb + 244 + j * TILE_WORDS] : 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
     float* pt = lds + (8 * g + kpar) * PS + fcol;
 #define P_PHASE(M0, OP)                                                                        \
     _Pragma("unroll") for (int mm = 0; mm < 2; ++mm)                                           \
-    _Pragma("unroll") for (int j = 0; j < FE_NT; ++j)                                          \
+    _Pragma("unroll") for (int j = 0; j < NTT; ++j)                                          \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
         float* cell = pt + (2 * (16 * ((M0) + mm) + r)) * PS + 16 * j;                         \
         const float v = sq[(M0) + mm][j][r >> 1][r & 1];                                       \
@@ -393,9 +405,9 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
     //      no bank conflicts), waves 0-1 take the bands below mel_split, waves 2-3 the rest; weights are LDS broadcasts
     //      of the packed non-zero taps.  Results go through a transposed LDS tile so that the stores are whole rows.
     {
-        const int tl = tid & 127;
-        const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
-        const int f_lo = half ? p.mel_split : 0, f_hi = half ? p.n_mels : p.mel_split;
+        const int tl = tid & (SLOTS - 1);
+        const int part = __builtin_amdgcn_readfirstlane(tid / SLOTS);
+        const int f_lo = p.mel_bounds[part], f_hi = p.mel_bounds[part + 1];
         float* outt = lds + OUT_OFF;
         if (tl < nfr) {
             const float* pr = lds + tl;
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
     // ---- log and x2 ("DCT of length 1") on the way out.  The values are read and finished into registers first; then
     //      (after a barrier) the next unit's samples go into the image region, and only then are the rows stored:
     //      waiting for the prefetched samples must not wait for this unit's stores (one counter covers both).
-    constexpr int COPY_IT = (FE_FRAMES * FE16_MAX_MELS + 255) / 256;
+    constexpr int COPY_IT = (FRM * FE16_MAX_MELS + 255) / 256;
     float outv[COPY_IT];
     const int nout = nfr * p.n_mels;
     {
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
         int tl = tid / p.n_mels, f = tid - tl * p.n_mels;
 #pragma unroll
         for (int it = 0; it < COPY_IT; ++it) {      // straight-line: elements past the end re-read the tile's last word
-            const float v = outt[min(tl * OUT_STRIDE + f, FE_FRAMES * OUT_STRIDE - 1)];
+            const float v = outt[min(tl * OUT_STRIDE + f, FRM * OUT_STRIDE - 1)];
             float lg = v >= 1e-30f ? __logf(v) : v;
             if (__builtin_expect(v > 0.f && v < 1e-30f, 0)) lg = logf(v);      // subnormal-range powers: the slow exact path
             outv[it] = 2.0f * lg;
@@ -482,6 +494,9 @@ __global__ __launch_bounds__(256, 2) void frontend_f16_kernel(FrontendParams p) 
     }
 }
 
+int frontend_f16_frames() { return FRM; }
+int frontend_f16_mel_parts() { return MEL_PARTS; }
+
 size_t frontend_f16_lds_bytes() {
     static_assert(FE_ROWS * PS <= IMG_WORDS, "power tile must fit the image region");
     const size_t words = (size_t)IMG_WORDS + CONST_WORDS + 4;
@@ -499,7 +514,7 @@ hipError_t launch_frontend_f16(const FrontendParams& p, int n_cu, hipStream_t s)
     }
     if (p.B <= 0) return hipSuccess;
     const long long units = (long long)p.B * p.chunks;
-    const dim3 grid((unsigned)std::min<long long>(units, 2LL * n_cu));      // persistent: two workgroups per CU
+    const dim3 grid((unsigned)std::min<long long>(units, (long long)WG_PER_CU * n_cu));      // persistent
     if (p.wav) hipLaunchKernelGGL(frontend_f16_kernel<0>, grid, dim3(256), lds, s, p);
     else if (!p.noise) hipLaunchKernelGGL(frontend_f16_kernel<1>, grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL(frontend_f16_kernel<2>, grid, dim3(256), lds, s, p);

@@ -84,7 +84,8 @@ struct kws_handle {
     // front end
     DevMem dft, hann, dft16, consts16, melw, mel_lo, mel_hi, edge_hann, edge_trig;
     bool fe_fp32 = false;                  // KWS_FRONTEND_IMPL=fp32: the fp32-input MFMA front end (frontend.hip)
-    int mel_maxw = 0, mel_ntaps = 0, mel_split = 0, mel_maxbin = 0;
+    int mel_maxw = 0, mel_ntaps = 0, mel_maxbin = 0;
+    int mel_bounds[5] = {0, 0, 0, 0, 0};
 
     // parameters
     std::set<std::string> required, loaded;
@@ -181,9 +182,9 @@ int setup_frontend(kws_handle* h) {
     build_dft_table_f16(tab16, hann2);
     if ((rc = h->dft16.upload(tab16.data(), tab16.size() * sizeof(unsigned)))) return rc;
     // constants of the fp16 front end, one blob: window; non-zero mel taps band after band; (first bin, tap offset)
-    // per band.  Its mel stage gives waves 0-1 the bands below mel_split and waves 2-3 the rest, two bands per step:
-    // split where the estimated cost (a fixed part per step + its groups of four taps) is halved, pad the two bands
-    // of a step to the same number of groups.
+    // per band.  Its mel stage works on 2 or 4 band ranges in parallel, two bands per step: the ranges split the
+    // estimated cost (a fixed part per step + its groups of four taps) evenly, the two bands of a step are padded to the
+    // same number of groups.
     std::vector<int> ng(d.n_mels);
     int cost_all = 0;
     for (int i = 0; i < d.n_mels; ++i) {
@@ -191,18 +192,15 @@ int setup_frontend(kws_handle* h) {
         cost_all += 4 + ng[i];
         h->mel_maxbin = std::max(h->mel_maxbin, hi[i]);
     }
-    h->mel_split = d.n_mels;
-    for (int i = 0, c = 0; i < d.n_mels; ++i) {
-        if (2 * c >= cost_all) {
-            h->mel_split = i;
-            break;
-        }
-        c += 4 + ng[i];
+    const int parts = frontend_f16_mel_parts();
+    h->mel_bounds[0] = 0;
+    for (int q = 1, i = 0, c = 0; q <= parts; ++q) {      // bounds[q] = first band at which q / parts of the cost is done
+        while (i < d.n_mels && parts * c < q * cost_all) c += 4 + ng[i++];
+        h->mel_bounds[q] = q == parts ? d.n_mels : i;
     }
-    for (int half = 0; half < 2; ++half) {
-        const int f0 = half ? h->mel_split : 0, f1 = half ? d.n_mels : h->mel_split;
-        for (int f = f0; f + 1 < f1; f += 2) ng[f] = ng[f + 1] = std::max(ng[f], ng[f + 1]);
-    }
+    for (int q = parts + 1; q <= 4; ++q) h->mel_bounds[q] = d.n_mels;
+    for (int q = 0; q < parts; ++q)
+        for (int f = h->mel_bounds[q]; f + 1 < h->mel_bounds[q + 1]; f += 2) ng[f] = ng[f + 1] = std::max(ng[f], ng[f + 1]);
     std::vector<float> blob(FE16_CONST_WORDS, 0.f);
     std::copy(hann2.begin(), hann2.end(), blob.begin());
     int* bandtab = reinterpret_cast<int*>(blob.data() + 256 + FE16_MAX_TAPS);
@@ -966,12 +964,18 @@ static int mfcc_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, con
     FrontendParams p{d_wav, reinterpret_cast<const short*>(d_pcm), d_noise, noise_pct, d_feat, h->dft.as<f32x4>(),
                      h->hann.as<float>(), h->melw.as<float>(), h->mel_lo.as<int>(), h->mel_hi.as<int>(), B, n_samples, T,
                      h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, h->mel_maxw, clip_stride < 0 ? n_samples : clip_stride,
-                     h->dft16.as<void>(), h->consts16.as<float>(), h->mel_split};
+                     h->dft16.as<void>(), h->consts16.as<float>(), {h->mel_bounds[0], h->mel_bounds[1], h->mel_bounds[2],
+                                                                    h->mel_bounds[3], h->mel_bounds[4]}};
     // the fp16 kernel reads whole 16-byte groups: rows (and base pointers) that are not 16-byte aligned -- odd clip
     // lengths, sliced buffers -- take the fp32-input kernel, which stages element-wise
     const bool aligned = (p.clip_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(d_wav) | reinterpret_cast<uintptr_t>(d_noise)) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(d_pcm) & 7) == 0;
-    HIP_TRY(h->fe_fp32 || !aligned ? launch_frontend(p, s) : launch_frontend_f16(p, h->n_cu, s));
+    if (h->fe_fp32 || !aligned) {
+        HIP_TRY(launch_frontend(p, s));
+    } else {
+        p.chunks = (T + frontend_f16_frames() - 1) / frontend_f16_frames();     // its units are shorter
+        HIP_TRY(launch_frontend_f16(p, h->n_cu, s));
+    }
     return prof_mark(h, h->ev_front, s);
 }
 

@@ -101,7 +101,7 @@ struct FrontendParams {
     long long clip_stride;   // samples between the starts of consecutive clips (n_samples for a packed batch)
     const void* dft16;    // fp16 two-part cos/sin fragments (frontend_f16x3.hip)
     const float* consts16;   // FE16_CONST_WORDS: h[j] (128), h[240-j] (128); mel taps; (first bin, tap offset) per band
-    int mel_split;           // first band of the upper half of the mel work
+    int mel_bounds[5];       // band ranges of the (2 or 4) parts of the mel work: part i = [bounds[i], bounds[i + 1])
 };
 constexpr int FE16_MAX_TAPS = 768, FE16_MAX_MELS = 40, FE16_MAX_BIN = 120;   // what frontend_f16_kernel's LDS tables hold
 constexpr int FE16_CONST_WORDS = 256 + FE16_MAX_TAPS + 2 * FE16_MAX_MELS + 4;
@@ -122,7 +122,9 @@ void build_edge_tables(std::vector<float>& hann, std::vector<float>& trig);
 size_t frontend_lds_bytes(int T);
 hipError_t launch_frontend(const FrontendParams& p, hipStream_t s);
 void build_dft_table(std::vector<float>& dft, std::vector<float>& hann);  // host side, double precision trig
-hipError_t launch_frontend_f16(const FrontendParams& p, int n_cu, hipStream_t s);     // frontend_f16x3.hip (default)
+hipError_t launch_frontend_f16(const FrontendParams& p, int n_cu, hipStream_t s);
+int frontend_f16_frames();      // frames per unit (chunk) of frontend_f16_kernel
+int frontend_f16_mel_parts();   // 2 or 4     // frontend_f16x3.hip (default)
 void build_dft_table_f16(std::vector<unsigned>& tab, std::vector<float>& hann2);
 
 // ---------------------------------------------------------------- fused res8 (res8_fused.hip)
