@@ -881,7 +881,7 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
                     std::vector<float> frag(3 * 3 * 64);
                     pack_res8_conv0(src, frag.data());
                     if ((rc = h->r8_w0a.upload(frag.data(), frag.size() * 4))) return rc;
-                    std::vector<unsigned short> w0h((size_t)3 * 2 * 64 * 8);
+                    std::vector<unsigned short> w0h((size_t)(3 * 2 + 3) * 64 * 8);
                     h->r8h_scale0 = weight_scale_pow2(src, n);
                     pack_res8h_conv0(src, h->r8h_scale0, w0h.data());
                     if ((rc = h->r8h_w0.upload(w0h.data(), w0h.size() * 2))) return rc;

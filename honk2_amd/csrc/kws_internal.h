@@ -194,7 +194,7 @@ struct Res8hParams {
 size_t res8h_lds_bytes();
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s);
 void pack_res8h_layer(const float* w /*45x45x3x3*/, float scale, unsigned short* dst /*R8X_KSTEPS*3*2*64*8*/);
-void pack_res8h_conv0(const float* w /*45x9*/, float scale, unsigned short* dst /*3*2*64*8*/);
+void pack_res8h_conv0(const float* w /*45x9*/, float scale, unsigned short* dst /*(3*2 + 3)*64*8*/);
 
 // ---------------------------------------------------------------- layer-wise kernels (layerwise.hip)
 struct ConvGeom {

@@ -397,11 +397,13 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         R8H_TS(1)
 
         // ---- conv_0 + ReLU + AvgPool(4,3) on the fp16 matrix cores, result in accumulator layout = prev_x.
-        //      K = 9 taps sit in k-slots 0..8 of one 16x16x32 step: lane group 0 supplies taps 0..7, group 1 tap 8, the rest
-        //      zeros.  Every lane reads eight staged words at compile-time offsets from its window base (group 1's base is
-        //      shifted onto tap 8) and v_perm_b32 gathers the fp16 halves into the two B fragments; per-lane selectors blank
-        //      the k-slots a lane group does not own.  Three terms as in the layers; 2^-S and the 1/12 of the pool ride on
-        //      one multiply.
+        //      K = 9 is so short that all THREE terms of the fp32-accurate product fit one 16x16x32 step side by side:
+        //      lane group 0 holds (w1, x1) for taps 0..7, group 1 (w1, x2), group 2 (w2, x1), group 3 the three
+        //      products of tap 8 -- one MFMA per (position tile, window member, channel tile) instead of three (648 ->
+        //      216 per wave and clip).  Every lane reads eight staged words (both fp16 parts of a feature) at
+        //      compile-time offsets from its window base (group 3's base is shifted onto tap 8) and v_perm_b32 gathers the
+        //      halves its group needs.  TERMS == 1 (plain fp16 operands) keeps the one-term layout: taps 0..7 on group 0,
+        //      tap 8 on group 1.  2^-S and the 1/12 of the pool ride on one multiply.
         f32x4 prev[5][3], prevx;
         {
             int lbw[6];   // byte address of the window base of this lane's position in each tile (+ tap 8 for lane group 1)
@@ -412,19 +414,30 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                 const int nn = n < R8_NPOS ? n : R8_NPOS - 1;
                 const int y = nn / W8_W;
                 const int x = nn - y * W8_W;
-                lbw[j] = (4 * y * FS + 3 * x + (g == 1 ? 2 * FS + 2 : 0)) * 4;
+                lbw[j] = (4 * y * FS + 3 * x + (g == (TERMS >= 3 ? 3 : 1) ? 2 * FS + 2 : 0)) * 4;
             }
             // selectors: low halves = part 1, high halves = part 2 of (even word, odd word); 0x0c bytes give zero
             const unsigned sel_h0 = g == 0 ? 0x05040100u : (g == 1 ? 0x0c0c0100u : 0x0c0c0c0cu);
             const unsigned sel_l0 = g == 0 ? 0x07060302u : (g == 1 ? 0x0c0c0302u : 0x0c0c0c0cu);
             const unsigned sel_h = g == 0 ? 0x05040100u : 0x0c0c0c0cu;
             const unsigned sel_l = g == 0 ? 0x07060302u : 0x0c0c0c0cu;
+            // K-packed form: groups 0 and 2 take part 1 of words (2i, 2i+1), group 1 part 2; group 3 takes both halves of
+            // word 0 (x1, x2 of tap 8), then x1 of tap 8 again (word 0 is substituted for word 2 on that group) and zeros
+            const unsigned selk_a = g == 1 ? 0x07060302u : (g == 3 ? 0x03020100u : 0x05040100u);
+            const unsigned selk_b = g == 1 ? 0x07060302u : (g == 3 ? 0x0c0c0100u : 0x05040100u);
+            const unsigned selk_c = g == 1 ? 0x07060302u : (g == 3 ? 0x0c0c0c0cu : 0x05040100u);
             u32x4 a0[3][2];
             const u32x4* A0 = reinterpret_cast<const u32x4*>(p.w0h) + lane;
 #pragma unroll
-            for (int m = 0; m < 3; ++m)
+            for (int m = 0; m < 3; ++m) {
+                if (TERMS >= 3) {
+                    a0[m][0] = A0[(6 + m) * 64];      // the K-packed fragments follow the two-part ones
+                    a0[m][1] = a0[m][0];
+                } else {
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt) a0[m][pt] = A0[(m * 2 + pt) * 64];
+                    for (int pt = 0; pt < 2; ++pt) a0[m][pt] = A0[(m * 2 + pt) * 64];
+                }
+            }
             const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
             const float post = p.inv_scale0 * (1.0f / 12.0f);
             const char* fb = reinterpret_cast<const char*>(feat_w);
@@ -441,6 +454,16 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
             BL[i] = __builtin_amdgcn_perm(w_[2 * i + 1], w_[2 * i], sel_l);                                    \
         }                                                                                                      \
     }
+#define C0_FRAGK(LB, OY, OX, BK)                                                                               \
+    {                                                                                                          \
+        unsigned w_[8];                                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                          \
+            w_[e] = *reinterpret_cast<const unsigned*>(fb + (LB) + (((OY) + e / 3) * FS + (OX) + e % 3) * 4);  \
+        BK[0] = __builtin_amdgcn_perm(w_[1], w_[0], selk_a);                                                   \
+        BK[1] = __builtin_amdgcn_perm(w_[3], g == 3 ? w_[0] : w_[2], selk_b);                                  \
+        BK[2] = __builtin_amdgcn_perm(w_[5], w_[4], selk_c);                                                   \
+        BK[3] = __builtin_amdgcn_perm(w_[7], w_[6], selk_c);                                                   \
+    }
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 f32x4 s0 = zero, s1 = zero, s2 = zero;
@@ -449,17 +472,26 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                     for (int wi = 0; wi < 12; ++wi) {
                         const int oy = wi / 3, ox = wi - 3 * oy;
                         u32x4 bh, bl;
-                        C0_FRAG(lbw[j], oy, ox, bh, bl)
                         f32x4 cc[3];
+                        if (TERMS >= 3) {
+                            C0_FRAGK(lbw[j], oy, ox, bh)
 #pragma unroll
-                        for (int m = 0; m < 3; ++m) {
-                            cc[m] = zero;
-                            MF(a0[m][1], bh, cc[m]);
+                            for (int m = 0; m < 3; ++m) {
+                                cc[m] = zero;
+                                MF(a0[m][0], bh, cc[m]);
+                            }
+                        } else {
+                            C0_FRAG(lbw[j], oy, ox, bh, bl)
+#pragma unroll
+                            for (int m = 0; m < 3; ++m) {
+                                cc[m] = zero;
+                                MF(a0[m][1], bh, cc[m]);
+                            }
+#pragma unroll
+                            for (int m = 0; m < 3; ++m) { MF(a0[m][0], bl, cc[m]); }
+#pragma unroll
+                            for (int m = 0; m < 3; ++m) { MF(a0[m][0], bh, cc[m]); }
                         }
-#pragma unroll
-                        for (int m = 0; m < 3; ++m) { MF(a0[m][0], bl, cc[m]); }
-#pragma unroll
-                        for (int m = 0; m < 3; ++m) { MF(a0[m][0], bh, cc[m]); }
                         s0 += relu4(cc[0]);
                         s1 += relu4(cc[1]);
                         s2 += relu4(cc[2]);
@@ -476,17 +508,25 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                     for (int wi = 0; wi < 12; ++wi) {
                         const int oy = wi / 3, ox = wi - 3 * oy;
                         u32x4 bh, bl;
-                        C0_FRAG(lbw[5], oy, ox, bh, bl)
                         f32x4 cx = zero;
-                        if (mx == 0) { MF(a0[0][1], bh, cx); MF(a0[0][0], bl, cx); MF(a0[0][0], bh, cx); }
-                        else if (mx == 1) { MF(a0[1][1], bh, cx); MF(a0[1][0], bl, cx); MF(a0[1][0], bh, cx); }
-                        else { MF(a0[2][1], bh, cx); MF(a0[2][0], bl, cx); MF(a0[2][0], bh, cx); }
+                        if (TERMS >= 3) {
+                            C0_FRAGK(lbw[5], oy, ox, bh)
+                            if (mx == 0) { MF(a0[0][0], bh, cx); }
+                            else if (mx == 1) { MF(a0[1][0], bh, cx); }
+                            else { MF(a0[2][0], bh, cx); }
+                        } else {
+                            C0_FRAG(lbw[5], oy, ox, bh, bl)
+                            if (mx == 0) { MF(a0[0][1], bh, cx); MF(a0[0][0], bl, cx); MF(a0[0][0], bh, cx); }
+                            else if (mx == 1) { MF(a0[1][1], bh, cx); MF(a0[1][0], bl, cx); MF(a0[1][0], bh, cx); }
+                            else { MF(a0[2][1], bh, cx); MF(a0[2][0], bl, cx); MF(a0[2][0], bh, cx); }
+                        }
                         sx += relu4(cx);
                     }
                 }
                 prevx = sx * post;
             }
 #undef C0_FRAG
+#undef C0_FRAGK
         }
         R8H_TS(2)
         // every wave is done with the staged features: turn the region back into an all-zero map (halo cells included), then
@@ -557,17 +597,30 @@ hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------- host packing
 // conv_0 weight (45, 9) times `scale` -> [channel tile 3][part 2][lane 64][8 fp16]: cout = 16 m + (lane & 15), k-slot
-// 8 (lane >> 4) + j holds tap k for k < 9, zeros otherwise
+// 8 (lane >> 4) + j holds tap k for k < 9, zeros otherwise; then [channel tile 3][lane 64][8 fp16] K-packed (below)
 void pack_res8h_conv0(const float* wt, float scale, unsigned short* dst) {
     for (int m = 0; m < 3; ++m)
         for (int lane = 0; lane < 64; ++lane) {
-            const int co = 16 * m + (lane & 15);
+            const int co = 16 * m + (lane & 15), g = lane >> 4;
             for (int j = 0; j < 8; ++j) {
-                const int k = 8 * (lane >> 4) + j;
+                const int k = 8 * g + j;
                 const float v = (k < 9 && co < R8_C) ? wt[co * 9 + k] * scale : 0.f;
                 const unsigned short h = f16_rne_host(v);
                 dst[((m * 2 + 0) * 64 + lane) * 8 + j] = h;
                 dst[((m * 2 + 1) * 64 + lane) * 8 + j] = f16_rne_host(v - f16_to_f_host(h));
+            }
+            // K-packed fragment (fragments 6..8): the three terms side by side -- lane group 0: w1 of taps 0..7 (meets x1),
+            // group 1: w1 again (meets x2), group 2: w2 (meets x1), group 3: tap 8 as (w1, w1, w2) against (x1, x2, x1)
+            for (int j = 0; j < 8; ++j) {
+                const int tap = g < 3 ? j : (j < 3 ? 8 : -1);
+                const bool low = g == 2 || (g == 3 && j == 2);
+                unsigned short out = 0;
+                if (tap >= 0 && co < R8_C) {
+                    const float v = wt[co * 9 + tap] * scale;
+                    const unsigned short h = f16_rne_host(v);
+                    out = low ? f16_rne_host(v - f16_to_f_host(h)) : h;
+                }
+                dst[((6 + m) * 64 + lane) * 8 + j] = out;
             }
         }
 }
