@@ -890,7 +890,7 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
                     pack_res8x_layer(src, h->r8x_apk_host.data() + (size_t)(idx - 1) * R8X_KSTEPS * 3 * 3 * 64 * 8);
                     h->r8h_scale[idx - 1] = weight_scale_pow2(src, n);
                     pack_res8h_layer(src, h->r8h_scale[idx - 1],
-                                     h->r8h_apk_host.data() + (size_t)(idx - 1) * R8X_KSTEPS * 3 * 2 * 64 * 8);
+                                     h->r8h_apk_host.data() + (size_t)(idx - 1) * R8H_ASTEPS * 3 * 2 * 64 * 8);
                 }
             }
         } else if (std::sscanf(name.c_str(), "layers.bn_%d.%31s", &idx, field) == 2) {

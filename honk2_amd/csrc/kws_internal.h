@@ -175,7 +175,8 @@ hipError_t launch_res8x(const Res8xParams& p, int grid, hipStream_t s);
 void pack_res8x_layer(const float* w /*45x45x3x3*/, unsigned short* dst /*R8X_KSTEPS*3*3*64*8*/);
 
 // ---------------------------------------------------------------- fused res8, fp16 three-term matrix path (res8_f16x3.hip)
-constexpr size_t R8H_APK_SHORTS = (size_t)R8_LAYERS * R8X_KSTEPS * 3 * 2 * 64 * 8;
+constexpr int R8H_ASTEPS = R8X_KSTEPS + 1;   // the 14 k-steps + the merged fragments of the last one (res8_f16x3.hip)
+constexpr size_t R8H_APK_SHORTS = (size_t)R8_LAYERS * R8H_ASTEPS * 3 * 2 * 64 * 8;
 
 struct Res8hParams {
     const float* feat;    // (B, 101, 40)
@@ -193,7 +194,7 @@ struct Res8hParams {
 };
 size_t res8h_lds_bytes();
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s);
-void pack_res8h_layer(const float* w /*45x45x3x3*/, float scale, unsigned short* dst /*R8X_KSTEPS*3*2*64*8*/);
+void pack_res8h_layer(const float* w /*45x45x3x3*/, float scale, unsigned short* dst /*R8H_ASTEPS*3*2*64*8*/);
 void pack_res8h_conv0(const float* w /*45x9*/, float scale, unsigned short* dst /*(3*2 + 3)*64*8*/);
 
 // ---------------------------------------------------------------- layer-wise kernels (layerwise.hip)

@@ -149,27 +149,30 @@ __device__ __forceinline__ void load_a(AFrags& f, const u32x4* A, int s, int mx)
         for (int pt = 0; pt < 2; ++pt) f.a[m][pt] = As[(m * 2 + pt) * 64];
     (void)mx;
 }
-__device__ __forceinline__ void load_b(BFrag& b, const char* lds, int addr) {
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) b.p[pt] = *reinterpret_cast<const u32x4*>(lds + addr + pt * PART_B);
+// fragment 0 from byte address a0, fragment 1 from a1 (a regular k-step: the two parts of one cell, a1 = a0 + PART_B)
+__device__ __forceinline__ void load_b(BFrag& b, const char* lds, int a0, int a1) {
+    b.p[0] = *reinterpret_cast<const u32x4*>(lds + a0);
+    b.p[1] = *reinterpret_cast<const u32x4*>(lds + a1);
 }
 
-// One k-step: 16 tiles x 6 terms = 96 MFMAs.  B fragments are fetched ONE position tile ahead (three ds_read_b128 in
-// flight -- the LDS counter is 4 bits, a whole k-step's 18 reads cannot be outstanding); `bnext_addr0` is tile 0 of
-// the NEXT k-step.  A fragments of the next k-step were requested by the caller before this step's MFMAs.
-#define X_STEP(AF, BOFF, BOFF_NEXT)                                                   \
+// One k-step: 16 tiles x 3 terms.  B fragments are fetched ONE position tile ahead (two ds_read_b128 in flight -- the LDS
+// counter is 4 bits, a whole k-step's reads cannot be outstanding); (OA_NEXT, OB_NEXT) address tile 0 of the NEXT k-step.
+// A fragments of the next k-step were requested by the caller before this step's MFMAs.  MFS(m, B, C) issues the step's
+// MFMAs of channel tile m.
+#define X_STEP(MFS, OA, OB, OA_NEXT, OB_NEXT)                                         \
     {                                                                                 \
         _Pragma("unroll") for (int j = 0; j < 6; ++j) {                               \
             BFrag& bcur = (j & 1) ? bb1 : bb0;                                        \
             BFrag& bnxt = (j & 1) ? bb0 : bb1;                                        \
-            load_b(bnxt, c.lds, j < 5 ? c.qb[j + 1] + (BOFF) : c.qb[0] + (BOFF_NEXT)); \
+            if (j < 5) load_b(bnxt, c.lds, c.qb[j + 1] + (OA), c.qb[j + 1] + (OB));   \
+            else load_b(bnxt, c.lds, c.qb[0] + (OA_NEXT), c.qb[0] + (OB_NEXT));       \
             __builtin_amdgcn_sched_barrier(0);                                        \
             if (j < 5) {                                                              \
-                _Pragma("unroll") for (int m = 0; m < 3; ++m) { MF6(AF.a[m], bcur.p, acc[j][m]) } \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) { MFS(m, bcur.p, acc[j][m]) } \
             } else {                                                                  \
-                if (c.mx == 0) { MF6(AF.a[0], bcur.p, accx) }                         \
-                else if (c.mx == 1) { MF6(AF.a[1], bcur.p, accx) }                    \
-                else { MF6(AF.a[2], bcur.p, accx) }                                   \
+                if (c.mx == 0) { MFS(0, bcur.p, accx) }                               \
+                else if (c.mx == 1) { MFS(1, bcur.p, accx) }                          \
+                else { MFS(2, bcur.p, accx) }                                         \
             }                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                        \
         }                                                                             \
@@ -186,27 +189,51 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
         for (int m = 0; m < 3; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     accx = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const u32x4* A = reinterpret_cast<const u32x4*>(p.apk2) + (size_t)layer * KSTEPS * A_STEP + c.lane;
+    const u32x4* A = reinterpret_cast<const u32x4*>(p.apk2) + (size_t)layer * R8H_ASTEPS * A_STEP + c.lane;
     AFrags fa0, fa1;
     BFrag bb0, bb1;   // ping-pong over position tiles; 6 tiles per step keeps the parity aligned across steps
     load_a(fa0, A, 0, mx);
-    load_b(bb0, c.lds, c.qb[0] + step_boff(0, g));
+    load_b(bb0, c.lds, c.qb[0] + step_boff(0, g), c.qb[0] + step_boff(0, g) + PART_B);
+#define MFS0(M, B, C) MF6(fa0.a[M], B, C)
+#define MFS1(M, B, C) MF6(fa1.a[M], B, C)
 #define X_PAIR(S)                                                                                                  \
     {                                                                                                              \
         const int o0 = step_boff((S), g), o1 = step_boff((S) + 1, g),                                              \
                   o2 = step_boff((S) + 2 < KSTEPS ? (S) + 2 : KSTEPS - 1, g);                                      \
         load_a(fa1, A, (S) + 1, mx);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
-        X_STEP(fa0, o0, o1)                                                                                        \
+        X_STEP(MFS0, o0, o0 + PART_B, o1, o1 + PART_B)                                                             \
         load_a(fa0, A, (S) + 2 < KSTEPS ? (S) + 2 : KSTEPS - 1, mx); /* last one is a harmless re-read */          \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
-        X_STEP(fa1, o1, o2)                                                                                        \
+        X_STEP(MFS1, o1, o1 + PART_B, o2, o2 + PART_B)                                                             \
     }
     if (!(p.debug & 2)) {
+        if (TERMS >= 3) {
+            // The last k-step holds only blocks 52 and 53 (lane groups 0, 1): its a1 b1 and a1 b2 terms share ONE MFMA --
+            // groups 0, 1 read part 1 of the cells, groups 2, 3 part 2 of the same two blocks, against a fragment that
+            // carries a1 twice (k-step slot 14 of the packed weights) -- so the step costs 2 MFMAs per tile, not 3.
 #pragma unroll 1   // unrolled, the scheduler hoists weight loads of later steps and spills at 256 registers
-        for (int s = 0; s < KSTEPS; s += 2) X_PAIR(s)
+            for (int s = 0; s < KSTEPS - 2; s += 2) X_PAIR(s)
+            const int o12 = step_boff(KSTEPS - 2, g), o13 = step_boff(KSTEPS - 1, g);
+            const int om = step_boff(KSTEPS - 1, g & 1) + (g >> 1) * PART_B;      // merged fragment: block 52 + (g & 1), part g >> 1
+            load_a(fa1, A, KSTEPS - 1, mx);
+            __builtin_amdgcn_sched_barrier(0);
+            X_STEP(MFS0, o12, o12 + PART_B, om, o13)
+            load_a(fa0, A, KSTEPS, mx);                                            // fa0.a[m][0] = (a1 | a1)
+            __builtin_amdgcn_sched_barrier(0);
+#define MFSL(M, B, C)            \
+    MF(fa1.a[M][1], B[1], C);    \
+    MF(fa0.a[M][0], B[0], C);
+            X_STEP(MFSL, om, o13, om, o13)                                         // (the last prefetch is a harmless re-read)
+#undef MFSL
+        } else {
+#pragma unroll 1
+            for (int s = 0; s < KSTEPS; s += 2) X_PAIR(s)
+        }
     }
 #undef X_PAIR
+#undef MFS0
+#undef MFS1
 
     // ---- epilogue in fp32: ReLU, residual (reference: even i), BatchNorm as one FMA.  The accumulators carry the layer's
     //      weight scale 2^S; 2^-S rides on the residual FMA (even layers) or is already folded into the BatchNorm scale of
@@ -628,22 +655,34 @@ void pack_res8h_conv0(const float* wt, float scale, unsigned short* dst) {
 // conv_i weight (45,45,3,3) times `scale` -> [k-step 14][channel tile 3][part 2][lane 64][8 fp16]:
 //   cout = 16 m + (lane & 15); block bi = 4 s + (lane >> 4): tap = bi / 6, input channels 8 (bi % 6) .. +7; bi >= 54: zeros
 void pack_res8h_layer(const float* wt, float scale, unsigned short* dst) {
+    auto weight = [&](int co, int bi, int j, bool low) -> unsigned short {
+        float v = 0.f;
+        if (bi < 54 && co < R8_C) {
+            const int tap = bi / 6, ci = 8 * (bi % 6) + j;
+            if (ci < R8_C) v = wt[((size_t)co * R8_C + ci) * 9 + tap] * scale;
+        }
+        const unsigned short h = f16_rne_host(v);
+        return low ? f16_rne_host(v - f16_to_f_host(h)) : h;
+    };
     for (int s = 0; s < KSTEPS; ++s)
         for (int m = 0; m < 3; ++m)
             for (int lane = 0; lane < 64; ++lane) {
                 const int co = 16 * m + (lane & 15), bi = 4 * s + (lane >> 4);
                 for (int j = 0; j < 8; ++j) {
-                    float v = 0.f;
-                    if (bi < 54 && co < R8_C) {
-                        const int tap = bi / 6, ci = 8 * (bi % 6) + j;
-                        if (ci < R8_C) v = wt[((size_t)co * R8_C + ci) * 9 + tap] * scale;
-                    }
-                    const unsigned short h = f16_rne_host(v);
-                    const unsigned short l = f16_rne_host(v - f16_to_f_host(h));
-                    dst[((((size_t)s * 3 + m) * 2 + 0) * 64 + lane) * 8 + j] = h;
-                    dst[((((size_t)s * 3 + m) * 2 + 1) * 64 + lane) * 8 + j] = l;
+                    dst[((((size_t)s * 3 + m) * 2 + 0) * 64 + lane) * 8 + j] = weight(co, bi, j, false);
+                    dst[((((size_t)s * 3 + m) * 2 + 1) * 64 + lane) * 8 + j] = weight(co, bi, j, true);
                 }
             }
+    // slot 14: part 1 of the last k-step's two real blocks (52, 53) on lane groups 0, 1 AND on groups 2, 3 -- the merged
+    // fragment that meets (part 1 | part 2) of the activations in one MFMA; its second fragment is unused (zero)
+    for (int m = 0; m < 3; ++m)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int co = 16 * m + (lane & 15), bi = 4 * (KSTEPS - 1) + ((lane >> 4) & 1);
+            for (int j = 0; j < 8; ++j) {
+                dst[((((size_t)KSTEPS * 3 + m) * 2 + 0) * 64 + lane) * 8 + j] = weight(co, bi, j, false);
+                dst[((((size_t)KSTEPS * 3 + m) * 2 + 1) * 64 + lane) * 8 + j] = 0;
+            }
+        }
 }
 
 }  // namespace kws
