@@ -556,8 +556,8 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 #undef C0_FRAGK
         }
         R8H_TS(2)
-        // every wave is done with the staged features: turn the region back into an all-zero map (halo cells included), then
-        // write the pooled conv_0 output into its interior
+        // every wave is done with the staged features: turn the region back into a map -- zero halo, then the pooled conv_0
+        // output in its interior
         int shift;   // range guard of the map the next layer reads
         {
             float amax = 0.f;
@@ -571,9 +571,14 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
             guard_push(reinterpret_cast<unsigned*>(c.red), w, lane, amax);   // group 0; layer l uses group (l + 1) & 1
         }
         __syncthreads();
-        for (int i = tid; i < MAP_BYTES / 16; i += 256) reinterpret_cast<u32x4*>(ldsb)[i] = (u32x4){0u, 0u, 0u, 0u};
+        // Only the 59 cells outside the 25 x 13 interior need clearing (map row 0, the shared halo cell in front of every
+        // row, everything from map row 26 on): the interior is overwritten right below, all 48 channel slots of both parts.
+        for (int t = tid; t < 59 * 12; t += 256) {
+            const int hc = t / 12, sub = t - 12 * hc;
+            const int cell = hc < 14 ? hc : (hc < 39 ? R8_RS * (hc - 13) : R8_RS * 26 + (hc - 39));
+            *reinterpret_cast<u32x4*>(ldsb + (sub / 6) * PART_B + cell * CELL_B + (sub % 6) * 16) = (u32x4){0u, 0u, 0u, 0u};
+        }
         shift = __builtin_amdgcn_readfirstlane(range_shift(guard_read(reinterpret_cast<const unsigned*>(c.red))));
-        __syncthreads();
         {
             const float down = shift > 0 ? ldexpf(1.f, -shift) : 1.f;
 #pragma unroll
