@@ -269,6 +269,12 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     const int fcol = pcol < 4 ? 2 * pcol : (pcol < 12 ? 2 * pcol - 7 : 2 * pcol - 16);
     const int fb = XS * fcol;
 
+    // x[240] of every frame (the j = 0 / 240 pair of the Re rows), read before the k-loop: seven dependent LDS round trips
+    // would otherwise sit between the last MFMA and the epilogue
+    float c240[NTT];
+#pragma unroll
+    for (int j = 0; j < NTT; ++j) c240[j] = w < 2 ? tsg * lds[fb + 244 + j * TILE_WORDS] : 0.f;
+
     // ---- k-loop, software-pipelined by hand: the B fragment of step idx + 1 (LDS reads, fold, window, split: ~44
     //      VALU) is built in the shadow of the 12 MFMAs of step idx.  (Explicit one-MFMA-to-four-VALU scheduling
     //      groups were tried: no faster, and the group solver's compile time explodes on a block this size.)
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     f32x2 sq[4][NTT][2];
 #pragma unroll
     for (int j = 0; j < NTT; ++j) {
-        const float c = w < 2 ? tsg * lds[fb + 244 + j * TILE_WORDS] : 0.f;
+        const float c = c240[j];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
