@@ -340,7 +340,8 @@ size_t res8h_lds_bytes() { return (size_t)X_LDS_BYTES; }
 // per-SIMD, 502-register build of the same code took 18.0 ms.  The overlap is partial because at 256 registers hipcc emits
 // VGPR-accumulator MFMAs, which one wave can only issue at half rate (tools/mfma_dep_probe.cpp): alone in its k-loop a
 // workgroup does not fill the pipe.  Forcing AGPR accumulators splits the budget 128 / 128 and spills (18.2 ms); a
-// start-up stagger of the second workgroup changes nothing.
+// start-up stagger of the second workgroup changes nothing (re-checked in v8 with the second workgroup identified per
+// physical CU -- HW_ID / XCC_ID arrival counters -- and delays of 30 / 60 / 90 k ticks: 13.62 - 13.76 ms, noise).
 // phase timestamps for tools/r8_phases.py: build with -DR8H_TIMING (they overwrite the consumed feature rows)
 #ifdef R8H_TIMING
 #define R8H_TS_DECL unsigned long long ts[8];
