@@ -1,3 +1,4 @@
+"""Manual check (GPU box, from the repo root): the three fused res8 kernels against a float64 evaluation of the oracle."""
 import sys, os, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from conftest import load_golden_model

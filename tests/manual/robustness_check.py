@@ -1,3 +1,5 @@
+"""Manual check (GPU box, from the repo root): many random weight / input draws and batch sizes through the fused res8
+path against the oracle's torch engine."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from oracle import models, weights, frontend

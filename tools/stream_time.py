@@ -5,15 +5,14 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from honk2_amd.utils import AudioProcessor, find_cls
-from oracle import weights
 
 n_win = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 window, shift = 16000, 160
 stream = (0.1 * torch.randn((n_win - 1) * shift + window, device="cuda")).clamp(-1, 1)
 ap = AudioProcessor()
 cfg = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 12}
-model = find_cls("model.ResNet")(dict(cfg))
-model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.make_state_dict("ResNet", cfg, seed=7).items()})
+torch.manual_seed(7)
+model = find_cls("model.ResNet")(dict(cfg))          # default init: timing only
 model = model.to("cuda:0").eval()
 for name, fn in (("mfcc_windows", lambda: ap.compute_mfccs_windows(stream, window, shift)),
                  ("forward_windows", lambda: model.forward_windows(stream, window, shift))):
