@@ -9,10 +9,14 @@ A step = one pass of the hot path (kws_forward_wav: MFCC front end + res8) over 
 16 kHz one-second clips (default 65 536, BASELINE.json configs[3] / the north-star target batch), sharded
 contiguously over the N ranks (strong scaling: 65 536 / N clips per GPU), followed for N > 1 by the RCCL
 all-gather of the (B/N, 12) logits.  Waveforms are resident in HBM before the timed region starts.  Rank 0 prints
-ONE JSON line.  `roofline` is for the dominant kernel (the fused res8 kernel, fp32 matrix cores): algorithmic
-FLOPs per launch / its mean launch duration measured with HIP events on the launch stream inside the timed steps.
-`cpu_baseline` (rank 0, N = 1 only) times the CPU oracle ("port": numpy/scipy rFFT front end + torch-CPU fp32
-model, parity-pinned against the reference in tests/) on a bounded sample of the same clips.
+ONE JSON line.  `roofline` is for the dominant kernel (the fused res8 kernel, fp32-accurate three-term fp16 products on the
+matrix cores): algorithmic FLOPs per launch / its mean launch duration measured with HIP events on the launch stream
+inside the timed steps.  `cpu_baseline` (rank 0, N = 1 only) times the CPU oracle ("port": numpy/scipy rFFT front end +
+torch-CPU fp32 model, parity-pinned against the reference in tests/) on a bounded sample of the same clips, and `parity`
+compares the GPU logits of exactly those clips with the oracle's (tolerance 1e-3, argmax); the run exits non-zero
+when that check fails.  Inputs: SURVEY.md section 8d, except that the 1 kHz tone clips carry their clip's noise at
+-37 dB as dither (a bare bin-centred sine leaves every off-peak mel band pure rounding noise, on which no two fp32
+implementations -- the reference's included -- agree); the `data` field says so.
 """
 import argparse
 import json
@@ -27,40 +31,60 @@ RES8 = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": Fal
 F_ALG_MODEL = 74.35e6          # FLOP / clip, conv + linear, 2 x MAC
 F_ALG_FRONTEND = 1.22e6        # FLOP / clip, FFT-based count
 B_ALG = 64048                  # HBM bytes / clip end to end: 16 000 fp32 samples in + 12 fp32 logits out
+B_BUILT = 96368                # what kws_forward_wav's two kernels move: + the (101, 40) fp32 feature map written and re-read
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input matrix (= fp32 vector) peak
 PEAK_BF16_MFMA_TFLOPS = 2516.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (spec); 2.0 PF sustained on this box (tools/coexec_probe_bf16)
 PEAK_HBM_GBS = 8000.0
+PMC_SUMMARIES = ("profiles/r02/final_summary.json", "profiles/r01/v8_summary.json")   # newest first
 
 
-def synth_wav(torch, n, seed, device):
-    """SURVEY.md section 8d inputs, generated on the device: 0.1*randn clamped to [-1,1]; every 12th clip exact
-    zeros; every 12th+1 a 0.5-amplitude 1 kHz tone (carrying the clip's noise at -37 dB as dither)."""
-    g = torch.Generator(device=device).manual_seed(seed)
+SYNTH_BLOCK = 1024
+
+
+def synth_wav(torch, lo, hi, seed, device):
+    """Clips [lo, hi) of the global synthetic batch, generated on the device: 0.1*randn clamped to
+    [-1,1]; every 12th clip exact zeros; every 12th+1 a 0.5-amplitude 1 kHz tone (carrying the clip's noise at -37 dB as
+    dither).  Clip i is a function of (seed, i) alone -- blocks of 1024 clips, one generator seed each -- so every
+    sharding of the batch sees the same clips."""
+    n = hi - lo
     wav = torch.empty((n, 16000), dtype=torch.float32, device=device)
-    for lo in range(0, n, 8192):
-        hi = min(n, lo + 8192)
-        wav[lo:hi] = (0.1 * torch.randn((hi - lo, 16000), generator=g, device=device)).clamp_(-1, 1)
+    for blk in range(lo // SYNTH_BLOCK, (hi + SYNTH_BLOCK - 1) // SYNTH_BLOCK):
+        g = torch.Generator(device=device).manual_seed(seed + blk)
+        x = (0.1 * torch.randn((SYNTH_BLOCK, 16000), generator=g, device=device)).clamp_(-1, 1)
+        a, b = max(lo, blk * SYNTH_BLOCK), min(hi, (blk + 1) * SYNTH_BLOCK)
+        wav[a - lo:b - lo] = x[a - blk * SYNTH_BLOCK:b - blk * SYNTH_BLOCK]
     t = torch.arange(16000, device=device, dtype=torch.float64) / 16000.0
     tone = (0.5 * torch.sin(2 * torch.pi * 1000.0 * t)).float()
-    wav[1::12] = tone + 0.05 * wav[1::12]
-    wav[0::12] = 0
+    idx = torch.arange(lo, hi, device=device)
+    tones = (idx % 12) == 1
+    wav[tones] = tone + 0.05 * wav[tones]
+    wav[(idx % 12) == 0] = 0
     return wav
 
 
 def build_model(torch, device):
-    import numpy as np
+    """res8 with the model's own default initialisation (torch.manual_seed(0)) and BatchNorm statistics randomised with
+    generator seed 1; returns the model and its state dict as numpy arrays for the CPU leg."""
     from honk2_amd.utils import find_cls
-    from oracle import weights   # deterministic weights shared with the cpu_baseline leg (bench-only use of oracle/)
-    sd = weights.make_state_dict("ResNet", RES8, seed=0)
+    torch.manual_seed(0)
     model = find_cls("model.ResNet")(dict(RES8))
-    model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()})
-    return model.to(device).eval(), sd
+    g = torch.Generator().manual_seed(1)
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_mean"):
+            sd[k] = 0.3 + 0.2 * torch.randn(v.shape, generator=g)
+        elif k.endswith("running_var"):
+            sd[k] = 0.25 + 0.5 * torch.rand(v.shape, generator=g)
+    model.load_state_dict(sd)
+    sd_np = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    return model.to(device).eval(), sd_np
 
 
 def cpu_baseline(torch, wav_sample, sd, budget_s=12.0):
-    """Time the CPU oracle on host cores over a bounded sample (about 10-20 s of CPU work)."""
+    """Time the CPU oracle on host cores over a bounded sample (about 10-20 s of CPU work).  Returns the record and the
+    oracle's logits for the clips it evaluated (the parity check compares the GPU's logits with them)."""
     import numpy as np
-    from oracle import frontend, models
+    from oracle import frontend, models    # bench-only use of oracle/: the checker and the timed CPU leg, never the product
     # the one-GPU box exposes every host core but grants a 16-worker share; stay inside the affinity mask and that share
     threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(threads)
@@ -76,12 +100,34 @@ def cpu_baseline(torch, wav_sample, sd, budget_s=12.0):
     per_clip = (time.perf_counter() - t0) / 256
     n = int(min(len(x), max(256, budget_s / max(per_clip, 1e-9))))
     n = max(256, n // 256 * 256)
+    outs = []
     t0 = time.perf_counter()
     for lo in range(0, n, 1024):
-        run(x[lo:lo + 1024])
+        outs.append(run(x[lo:lo + 1024]))
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"{n} of the benchmark's clips, chunks of 1024, numpy/scipy rFFT front end (fp32) + torch-CPU fp32 res8, {dt:.1f} s"}
+    want = np.concatenate([np.asarray(o) for o in outs], 0)[:n]
+    rec = {"value": n / dt, "unit": "clips/s", "cores": threads, "kind": "port",
+           "sample": f"{n} of the benchmark's clips, chunks of 1024, numpy/scipy rFFT front end (fp32) + torch-CPU fp32 res8, {dt:.1f} s"}
+    return rec, want
+
+
+def parity_record(got, want, tol=1e-3):
+    """GPU logits vs the oracle's on the same clips: the north-star bar (|diff| <= 1e-3, argmax equal).  With |diff| <= e on
+    every logit the argmax can only differ where the oracle's own top-1 / top-2 margin is below 2 e, so a mismatch on a
+    wider margin is a failure whatever the tolerance; mismatches on near-ties (two fp32 evaluations of the same
+    clip do not order a 1e-6 margin reliably) are reported, not hidden."""
+    import numpy as np
+    err = np.abs(got - want)
+    top = np.sort(want, axis=1)
+    margin = top[:, -1] - top[:, -2]
+    miss = got.argmax(1) != want.argmax(1)
+    max_err = float(err.max())
+    worst_margin = float(margin[miss].max()) if miss.any() else 0.0
+    ok = bool(np.isfinite(got).all() and max_err <= tol and worst_margin <= 2.0 * max_err + 1e-7)
+    return {"clips": int(len(want)), "max_abs_err": max_err, "tol": tol, "argmax_equal": bool(not miss.any()),
+            "argmax_mismatches": int(miss.sum()), "mismatch_max_margin": worst_margin,
+            "min_margin": float(margin.min()), "against": "cpu_baseline's oracle logits (fp32 port) on the same clips",
+            "pass": ok}
 
 
 def main():
@@ -104,7 +150,8 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
     # KWS_BENCH_BACKEND / KWS_BENCH_ONE_DEVICE are rehearsal knobs only (several ranks on one GPU over gloo, to exercise
     # the N > 1 code path on a single-GPU box); the real multi-GPU run uses RCCL with one GPU per rank.
-    rank, world = dist_utils.init_from_env(os.environ.get("KWS_BENCH_BACKEND", "nccl"))
+    backend = os.environ.get("KWS_BENCH_BACKEND", "nccl")
+    rank, world = dist_utils.init_from_env(backend)
     local = 0 if os.environ.get("KWS_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -112,7 +159,7 @@ def main():
     lo, hi = dist_utils.shard_bounds(args.batch, rank, world)
     nloc = hi - lo
     model, sd = build_model(torch, device)
-    wav = synth_wav(torch, nloc, 1234 + rank, device)
+    wav = synth_wav(torch, lo, hi, 1234, device)
     logits = torch.empty((nloc, RES8["n_labels"]), dtype=torch.float32, device=device)
     counts = [b - a for a, b in (dist_utils.shard_bounds(args.batch, r, world) for r in range(world))]
     gathered = torch.empty((args.batch, RES8["n_labels"]), dtype=torch.float32, device=device) if world > 1 else None
@@ -120,7 +167,9 @@ def main():
     def step():
         model.forward_wav(wav, out=logits)
         if world > 1:
-            if len(set(counts)) == 1:
+            if backend != "nccl":                                  # rehearsal over gloo: collectives on host copies
+                gathered.copy_(dist_utils.all_gather_rows(logits.cpu(), counts))
+            elif len(set(counts)) == 1:
                 dist.all_gather_into_tensor(gathered, logits)     # RCCL over xGMI: the path's only collective
             else:
                 gathered.copy_(dist_utils.all_gather_rows(logits, counts))
@@ -145,11 +194,12 @@ def main():
     model_ms, front_ms, calls = engine.profile_read()
     engine.profile_enable(False)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    assert torch.isfinite(logits).all()
+    if not bool(torch.isfinite(logits).all()):
+        raise SystemExit("non-finite logits")
 
     if rank == 0:
         clips_per_s = args.batch * args.steps / elapsed
@@ -176,33 +226,50 @@ def main():
         # HBM bytes per launch cannot be measured from inside the process; when the committed counter summary of this very
         # workload (same kernel, same clips per launch) is present, quote it: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate passes, KB units, x2 correction on the gfx950 fetch counter (MI355X_MICROARCH.md).
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "v8_summary.json")
-        if plan == "res8_fused" and nloc == 65536 and os.path.exists(pmc):
-            try:
-                with open(pmc) as f:
-                    summ = json.load(f)
-                ent = next(v for k, v in summ.items() if "res8h_kernel" in k)
-                roofline["traffic"] = (2.0 * ent["FETCH_SIZE"] + ent["WRITE_SIZE"]) * 1024.0
-                roofline["traffic_source"] = "profiles/r01/v8_summary.json (rocprofv3 --pmc, same command)"
-            except Exception:
-                pass
+        # (a STATIC figure: it describes the committed profile, not this very run)
+        if plan == "res8_fused" and nloc == 65536:
+            for rel in PMC_SUMMARIES:
+                pmc = os.path.join(ROOT, rel)
+                try:
+                    with open(pmc) as f:
+                        summ = json.load(f)
+                    ent = next(v for k, v in summ.items() if "res8h_kernel" in k)
+                    roofline["traffic"] = (2.0 * ent["FETCH_SIZE"] + ent["WRITE_SIZE"]) * 1024.0
+                    roofline["traffic_source"] = f"static: {rel} (rocprofv3 --pmc of this command, committed; not measured in this run)"
+                    break
+                except Exception:
+                    continue
         out = {
             "metric": "1s-clips/sec end-to-end (wav->logits), res8 GSCv2", "value": clips_per_s, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": ("f32 (f16x3: fp32-accurate 3-term fp16 products, fp32 accumulate, in the conv stack and in the front end's DFT)" if plan == "res8_fused" else "f32 (bf16x6: fp32-accurate 6-term bf16 products, fp32 accumulate; fp32 front end)" if plan == "res8_fused_bf16x6" else "f32"), "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": ("f32 (f16x3: fp32-accurate 3-term fp16 products, fp32 accumulate, in the conv stack and in the front end's DFT)" if plan == "res8_fused" else "f32 (bf16x6: fp32-accurate 6-term bf16 products, fp32 accumulate; fp32 front end)" if plan == "res8_fused_bf16x6" else "f32"), "data": "synthetic (SURVEY.md 8d inputs; deviation: the 1 kHz tone clips carry their clip's noise at -37 dB as dither)",
             "config": {"workload": f"res8 fp32 wav->logits, global batch {args.batch} one-second 16 kHz clips "
                                    f"(BASELINE configs[3]), {nloc} clips/GPU, random-init weights",
                        "global_batch": args.batch, "clips_per_gpu": nloc, "n_samples": 16000,
                        "plan": model.plan_name(), "parallelism": f"dp{world} (clip sharding, logits all-gather)"},
             "roofline": roofline,
-            "frontend": {"kernel": "frontend_kernel (STFT+mel+log, fp32 MFMA)", "kernel_ms": f_ms,
-                         "hbm_GBps_algorithmic": (80160 * nloc / (f_ms * 1e-3) / 1e9) if f_ms > 0 else 0.0},
+            "frontend": {"kernel": "frontend_f16_kernel (reflect pad + Hann + 480-point DFT as three-term fp16 MFMA products + mel + log)",
+                         "kernel_ms": f_ms, "bound": "hbm", "bytes_per_clip": 80160,
+                         "hbm_GBps_algorithmic": (80160 * nloc / (f_ms * 1e-3) / 1e9) if f_ms > 0 else 0.0,
+                         "frac_of_8TBps": (80160 * nloc / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if f_ms > 0 else 0.0},
+            "b_alg": {"end_to_end": B_ALG, "as_built": B_BUILT,
+                      "note": "kws_forward_wav runs two kernels: the (101,40) fp32 feature map is written to the workspace and re-read (+2 x 16 160 B/clip)"},
             "end_to_end": {"hbm_frac_of_8TBps": clips_per_s / world * B_ALG / (PEAK_HBM_GBS * 1e9),
+                           "hbm_frac_of_8TBps_as_built": clips_per_s / world * B_BUILT / (PEAK_HBM_GBS * 1e9),
                            "flop_frac_of_fp32_peak": clips_per_s / world * (F_ALG_MODEL + F_ALG_FRONTEND) / (PEAK_F32_MFMA_TFLOPS * 1e12)},
         }
+        failed = False
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(torch, wav[:16384], sd)
+            out["cpu_baseline"], want = cpu_baseline(torch, wav[:16384], sd)
+            out["parity"] = parity_record(logits[:len(want)].cpu().numpy(), want)
+            failed = not out["parity"]["pass"]
+        dump = os.environ.get("KWS_BENCH_DUMP")        # tests: the (gathered) logits of the last step, for comparison across N
+        if dump:
+            import numpy as np
+            np.save(dump, (gathered if world > 1 else logits).cpu().numpy())
         print(json.dumps(out))
+        if failed:
+            raise SystemExit("parity check failed: " + json.dumps(out["parity"]))
     if world > 1:
         dist.destroy_process_group()
 

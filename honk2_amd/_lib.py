@@ -134,15 +134,21 @@ class Engine:
     """Owns one kws_handle plus its torch-allocated workspace.  Device memory for I/O and scratch comes from
     PyTorch (plumbing); all arithmetic happens inside libkws_hip.so."""
 
-    def __init__(self, desc):
+    def __init__(self, desc, device=None):
+        """`device`: the GPU the handle lives on (weights, workspace, launches); default = torch's current device.
+        Every tensor handed to the compute methods must be on that device."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("honk2_amd: no ROCm device visible to PyTorch; the HIP path is mandatory (no CPU fallback)")
         self.lib = load()
         self.desc = desc
         self.handle = C.c_void_p()
-        check(self.lib.kws_create(C.byref(desc), C.byref(self.handle)), "kws_create")
-        self.device = torch.device("cuda", torch.cuda.current_device())
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("honk2_amd: an Engine needs a ROCm device; there is no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device.index is None else device.index)
+        with torch.cuda.device(self.device):               # kws_create binds the handle to the current HIP device
+            check(self.lib.kws_create(C.byref(desc), C.byref(self.handle)), "kws_create")
         self._ws = None
 
     def close(self):
@@ -178,15 +184,20 @@ class Engine:
             check(self.lib.kws_set_workspace(self.handle, C.c_void_p(self._ws.data_ptr()), self._ws.numel()),
                   "kws_set_workspace")
 
-    @staticmethod
-    def _stream():
+    def _stream(self):
         import torch
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)   # the caller's stream on the handle's device
+
+    def _on_device(self, t, what):
+        if t.device != self.device:
+            raise RuntimeError(f"honk2_amd: {what} is on {t.device} but this engine (weights, workspace) lives on "
+                               f"{self.device}; move the model with .to(...) or the tensor")
 
     def _check_in(self, t, ndim, what):
         import torch
         if not (isinstance(t, torch.Tensor) and t.is_cuda):
             raise RuntimeError(f"honk2_amd: {what} must be a CUDA(ROCm) tensor; there is no CPU path")
+        self._on_device(t, what)
         if t.dim() != ndim:
             raise ValueError(f"honk2_amd: {what} must have {ndim} dimensions, got {tuple(t.shape)}")
         return t.to(dtype=torch.float32).contiguous()
@@ -202,6 +213,7 @@ class Engine:
             raise RuntimeError("honk2_amd: wav must be a CUDA(ROCm) tensor; there is no CPU path")
         if wav.dim() != 2:
             raise ValueError(f"honk2_amd: wav must have 2 dimensions, got {tuple(wav.shape)}")
+        self._on_device(wav, "wav")
         pcm = wav.dtype == torch.int16
         wav = wav.contiguous() if pcm else wav.to(dtype=torch.float32).contiguous()
         if noise is not None:
@@ -305,6 +317,8 @@ class Engine:
         return out
 
     def eval_batch(self, logits, target, stats, loss_sum):
+        for t, what in ((logits, "logits"), (target, "target"), (stats, "stats"), (loss_sum, "loss_sum")):
+            self._on_device(t, what)
         check(self.lib.kws_eval_batch(self.handle, C.c_void_p(logits.data_ptr()), C.c_void_p(target.data_ptr()),
                                       logits.shape[0], C.c_void_p(stats.data_ptr()), C.c_void_p(loss_sum.data_ptr()),
                                       self._stream()), "kws_eval_batch")

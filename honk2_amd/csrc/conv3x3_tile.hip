@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
     constexpr int NGRP = 256 / NQ;     // cells copied per pass (21 / 42)
     constexpr int UNR = NB == 6 ? 10 : 5;  // staging passes in flight together
     extern __shared__ __align__(16) char lds[];
+    if (range_gate_closed(p.rg)) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
 
     // ---------------------------------------------------------------- epilogue
     char* const outp = reinterpret_cast<char*>(p.out);
+    float amax = 0.f;   // largest magnitude stored (fp16 range guard)
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         if (!valid[j]) continue;
@@ -324,10 +326,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
                 float x = relu1(fmaf(acc[j][m][r], p.inv_scale, bb[r]));   // inv_scale = 2^-S of the fp16 weights (1 for bf16)
                 if (resp) x += resv[j][m][r];
                 v[r] = co0 + r < p.Cout ? x : 0.f;   // padded channels hold exact zeros
+                amax = fmaxf(amax, fabsf(v[r]));
             }
             *reinterpret_cast<f32x4*>(outp + ocell + co0 * 4) = v;
         }
     }
+    range_note(p.rg, amax);
 }
 
 // one tile buffer (TILE_P + 2 Ws + 2 cells + the zero cell)
@@ -403,7 +407,8 @@ void pack_conv3x3_tile_weights_f16(int C, const float* w, float scale, std::vect
 // channels-last (B, H/kh, W/kw, cp) fp32, i.e. layout(1).  One thread: one output position x four channels.
 __global__ __launch_bounds__(256) void nchw_to_cl_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                          long long total, int C, int H, int W, int Hp, int Wp, int kh,
-                                                         int kw, int is_max, int cp) {
+                                                         int kw, int is_max, int cp, RangeGate rg) {
+    if (range_gate_closed(rg)) return;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int nq = cp / 4;
@@ -431,15 +436,19 @@ __global__ __launch_bounds__(256) void nchw_to_cl_kernel(const float* __restrict
         v[r] = x;
     }
     *reinterpret_cast<f32x4*>(out + ((b * Hp + oy) * (long long)Wp + ox) * cp + q * 4) = v;
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(v[r]));
+    range_note(rg, amax);
 }
 
 hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, int W, int kh, int kw, int is_max, int cp,
-                             hipStream_t s) {
+                             hipStream_t s, RangeGate rg) {
     const int Hp = H / kh, Wp = W / kw;
     const long long total = (long long)B * (cp / 4) * Hp * Wp;
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(nchw_to_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, C, H, W,
-                       Hp, Wp, kh, kw, is_max, cp);
+                       Hp, Wp, kh, kw, is_max, cp, rg);
     return hipGetLastError();
 }
 
@@ -449,8 +458,9 @@ hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, i
 __global__ __launch_bounds__(256) void mean_linear_cl_kernel(const float* __restrict__ x, float* __restrict__ logits,
                                                              int C, int cp, int HW, const float* mean, const float* rstd,
                                                              const float* __restrict__ wt, const float* __restrict__ bias,
-                                                             int n_out) {
+                                                             int n_out, RangeGate rg) {
     extern __shared__ float sm[];   // [nsl][cp] partial sums, then [cp] means
+    if (range_gate_closed(rg)) return;
     const int b = blockIdx.x;
     const int nsl = 256 / cp > 0 ? 256 / cp : 1;   // cell slices summed in parallel
     const int c = threadIdx.x % cp, sl = threadIdx.x / cp;
@@ -478,12 +488,12 @@ __global__ __launch_bounds__(256) void mean_linear_cl_kernel(const float* __rest
 }
 
 hipError_t launch_mean_linear_cl(const float* x, float* logits, int B, int C, int cp, int HW, const float* mean,
-                                 const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s) {
+                                 const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s, RangeGate rg) {
     if (B <= 0) return hipSuccess;
     if (cp > 256) return hipErrorInvalidValue;
     const int nsl = 256 / cp;
     hipLaunchKernelGGL(mean_linear_cl_kernel, dim3((unsigned)B), dim3(256), (size_t)(nsl + 1) * cp * sizeof(float), s, x,
-                       logits, C, cp, HW, mean, rstd, w, bias, n_out);
+                       logits, C, cp, HW, mean, rstd, w, bias, n_out, rg);
     return hipGetLastError();
 }
 

@@ -114,21 +114,38 @@ struct kws_handle {
     // workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    DevMem range_flag;                     // one device word: fp16 range guard of the layer-wise plans (kws_internal.h)
 
     // profiling
     bool prof = false;
-    std::vector<hipEvent_t> ev_model, ev_front;   // start/stop pairs
+    std::vector<hipEvent_t> ev_pool;              // created by kws_profile_enable, reused: no hipEventCreate in a timed call
+    size_t ev_next = 0;
+    std::vector<hipEvent_t> ev_model, ev_front;   // start/stop pairs (entries of ev_pool)
     double acc_model_ms = 0, acc_front_ms = 0;
     int acc_calls = 0;
     const char* last_plan = "none";
 
     ~kws_handle() {
-        for (auto e : ev_model) (void)hipEventDestroy(e);
-        for (auto e : ev_front) (void)hipEventDestroy(e);
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
     }
 };
 
 namespace {
+
+// A handle belongs to the device that was current in kws_create (weights, DFT tables, function attributes live there).
+// Every entry point that allocates, copies or launches makes that device current for the duration of the call and
+// restores the caller's, so a handle keeps working when the caller's current device has moved on (several GPUs driven
+// from one process, as the reference's DataParallel does).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const kws_handle* h) {
+        if (h && hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 
 // ---------------------------------------------------------------------------------------------- front end setup
 double hz_to_mel(double f) {
@@ -571,8 +588,12 @@ size_t act_bytes(const kws_handle* h, int B, int T) {
 // ---------------------------------------------------------------------------------------------- profiling helpers
 int prof_mark(kws_handle* h, std::vector<hipEvent_t>& v, hipStream_t s) {
     if (!h->prof) return KWS_OK;
-    hipEvent_t e;
-    HIP_TRY(hipEventCreate(&e));
+    if (h->ev_next == h->ev_pool.size()) {   // more calls between two reads than kws_profile_enable provided for
+        hipEvent_t ne;
+        HIP_TRY(hipEventCreate(&ne));
+        h->ev_pool.push_back(ne);
+    }
+    hipEvent_t e = h->ev_pool[h->ev_next++];
     v.push_back(e);
     HIP_TRY(hipEventRecord(e, s));
     return KWS_OK;
@@ -582,6 +603,21 @@ int prof_mark(kws_handle* h, std::vector<hipEvent_t>& v, hipStream_t s) {
 // ResNet, LDS-tiled plan: conv_0 (fp32 MFMA, NCHW out) -> pool / transpose to channels-last -> conv3x3_tile_kernel per
 // layer -> mean + Linear.  The residual stream alternates between two buffers because a layer reads prev_x in the
 // layout it was written in and writes the layout its consumer wants; odd layers write Y.
+// fp16 range guard (kws_internal.h, RangeGate): modes whose operands are fp16 parts run every chunk twice -- the second pass
+// on bf16 parts, gated by the device word the first pass sets when it stores a value fp16 cannot hold.
+bool guarded_mode(const kws_handle* h, int terms) { return (terms == 6 || terms == 16) && h->lw_mode != LW_FP32; }
+constexpr int RANGE_FREE_MODE = 66;
+
+template <class Pass>
+int run_guarded(kws_handle* h, int terms, hipStream_t s, Pass&& pass) {
+    if (!guarded_mode(h, terms)) return pass(terms, RangeGate{nullptr, 0});
+    unsigned* flag = h->range_flag.as<unsigned>();
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), s));
+    int rc = pass(terms, RangeGate{flag, 0});
+    if (rc) return rc;
+    return pass(RANGE_FREE_MODE, RangeGate{flag, 1});
+}
+
 int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
     const kws_model_desc& d = h->d;
     const ResnetShape sh = resnet_shape(h, T);
@@ -592,46 +628,51 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
     float* X = (float*)ws; ws += align256(cl * cb * 4);
     float* X2 = (float*)ws; ws += align256(cl * cb * 4);
     float* Y = (float*)ws;
-    const int terms = dtype_terms(d.dtype);
     int rc;
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
+        // conv_0 runs on the fp32-input MFMA: no fp16 operands, one launch serves both passes (bufA is not overwritten)
         ConvGeom g0 = h->rconv[0].g;
         set_spatial(g0, nb, sh.T, sh.F);
         ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, bufA, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr, nullptr};
-        if ((rc = launch_layer(h->rconv[0], g0, a0, s, terms))) return rc;
-        HIP_TRY(launch_nchw_to_cl(bufA, X, nb, C, sh.T, sh.F, sh.pooled ? d.pool_h : 1, sh.pooled ? d.pool_w : 1, 0, cp, s));
-        float* xc = X;
-        float* xn = X2;
-        int ld_x = 0;   // layout of xc
-        for (int i = 1; i <= d.n_layers; ++i) {
-            const int ld_in = ilog2(resnet_dilation(d, i));
-            const int ld_out = i < d.n_layers ? ilog2(resnet_dilation(d, i + 1)) : 0;
-            const int dd = 1 << ld_in;
-            const bool even = (i % 2) == 0;
-            TileConvParams tp{};
-            tp.in = even ? Y : xc;
-            tp.out = even ? xn : Y;
-            tp.res = even ? xc : nullptr;
-            decode_mode(terms, tp.f16, tp.terms);
-            tp.apk16 = tp.f16 ? h->rconv[i].apk_t3h.as<unsigned short>() : h->rconv[i].apk16.as<unsigned short>();
-            tp.inv_scale = tp.f16 ? 1.0f / h->rconv[i].t3h_scale : 1.0f;
-            tp.border = h->rconv[i].has_border ? h->rconv[i].border_pad.as<float>() : nullptr;
-            tp.B = nb; tp.H = sh.H; tp.W = sh.W; tp.Cout = C;
-            tp.ld_in = ld_in; tp.ld_out = ld_out; tp.ld_res = ld_x;
-            tp.Hs = (sh.H + dd - 1) / dd; tp.Ws = (sh.W + dd - 1) / dd;
-            tp.total = nb * dd * dd * tp.Hs * tp.Ws;
-            HIP_TRY(launch_conv3x3_tile(tp, C, s));
-            if (even) {
-                std::swap(xc, xn);
-                ld_x = ld_out;
+        if ((rc = launch_layer(h->rconv[0], g0, a0, s, dtype_terms(d.dtype)))) return rc;
+        auto pass = [&](int terms, RangeGate rg) -> int {
+            HIP_TRY(launch_nchw_to_cl(bufA, X, nb, C, sh.T, sh.F, sh.pooled ? d.pool_h : 1, sh.pooled ? d.pool_w : 1, 0, cp, s, rg));
+            float* xc = X;
+            float* xn = X2;
+            int ld_x = 0;   // layout of xc
+            for (int i = 1; i <= d.n_layers; ++i) {
+                const int ld_in = ilog2(resnet_dilation(d, i));
+                const int ld_out = i < d.n_layers ? ilog2(resnet_dilation(d, i + 1)) : 0;
+                const int dd = 1 << ld_in;
+                const bool even = (i % 2) == 0;
+                TileConvParams tp{};
+                tp.in = even ? Y : xc;
+                tp.out = even ? xn : Y;
+                tp.res = even ? xc : nullptr;
+                decode_mode(terms, tp.f16, tp.terms);
+                tp.apk16 = tp.f16 ? h->rconv[i].apk_t3h.as<unsigned short>() : h->rconv[i].apk16.as<unsigned short>();
+                tp.inv_scale = tp.f16 ? 1.0f / h->rconv[i].t3h_scale : 1.0f;
+                tp.border = h->rconv[i].has_border ? h->rconv[i].border_pad.as<float>() : nullptr;
+                tp.B = nb; tp.H = sh.H; tp.W = sh.W; tp.Cout = C;
+                tp.ld_in = ld_in; tp.ld_out = ld_out; tp.ld_res = ld_x;
+                tp.Hs = (sh.H + dd - 1) / dd; tp.Ws = (sh.W + dd - 1) / dd;
+                tp.total = nb * dd * dd * tp.Hs * tp.Ws;
+                tp.rg = rg;
+                HIP_TRY(launch_conv3x3_tile(tp, C, s));
+                if (even) {
+                    std::swap(xc, xn);
+                    ld_x = ld_out;
+                }
             }
-        }
-        const float* fin = (d.n_layers % 2 == 0) ? xc : Y;
-        HIP_TRY(launch_mean_linear_cl(fin, logits + (size_t)b0 * d.n_labels, nb, C, cp, sh.H * sh.W,
-                                      h->bn_mean.as<float>() + (size_t)(d.n_layers - 1) * C,
-                                      h->bn_rstd.as<float>() + (size_t)(d.n_layers - 1) * C, h->out_w.as<float>(),
-                                      h->out_b.as<float>(), d.n_labels, s));
+            const float* fin = (d.n_layers % 2 == 0) ? xc : Y;
+            HIP_TRY(launch_mean_linear_cl(fin, logits + (size_t)b0 * d.n_labels, nb, C, cp, sh.H * sh.W,
+                                          h->bn_mean.as<float>() + (size_t)(d.n_layers - 1) * C,
+                                          h->bn_rstd.as<float>() + (size_t)(d.n_layers - 1) * C, h->out_w.as<float>(),
+                                          h->out_b.as<float>(), d.n_labels, s, rg));
+            return KWS_OK;
+        };
+        if ((rc = run_guarded(h, dtype_terms(d.dtype), s, pass))) return rc;
     }
     return KWS_OK;
 }
@@ -648,30 +689,34 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
     float* X = (float*)ws; ws += align256(small * cb * 4);
     float* Y = (float*)ws;
     const int C = sh.C;
-    const int terms = dtype_terms(d.dtype);
     int rc;
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
-        // conv_0 + ReLU (+ AvgPool)
-        ConvGeom g0 = h->rconv[0].g;
-        set_spatial(g0, nb, sh.T, sh.F);
-        ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr, nullptr};
-        if ((rc = launch_layer(h->rconv[0], g0, a0, s, terms))) return rc;
-        if (sh.pooled) HIP_TRY(launch_pool(bufA, X, nb * C, sh.T, sh.F, d.pool_h, d.pool_w, 0, s));
-        // conv_i: odd i writes Y from X, even i accumulates into X from Y (prev_x lives in X)
-        for (int i = 1; i <= d.n_layers; ++i) {
-            ConvGeom g = h->rconv[i].g;
-            set_spatial(g, nb, sh.H, sh.W);
-            const bool even = (i % 2) == 0;
-            ConvArgs a{even ? Y : X, even ? X : Y, h->rconv[i].apk.as<float>(), nullptr, nullptr, nullptr,
-                       h->rconv[i].has_border ? h->rconv[i].border.as<float>() : nullptr};
-            if ((rc = launch_layer(h->rconv[i], g, a, s, terms))) return rc;
-        }
-        const float* fin = (d.n_layers % 2 == 0) ? X : Y;
-        HIP_TRY(launch_mean_linear(fin, logits + (size_t)b0 * d.n_labels, nb, C, sh.H * sh.W,
-                                   h->bn_mean.as<float>() + (size_t)(d.n_layers - 1) * C,
-                                   h->bn_rstd.as<float>() + (size_t)(d.n_layers - 1) * C, h->out_w.as<float>(),
-                                   h->out_b.as<float>(), d.n_labels, s));
+        auto pass = [&](int terms, RangeGate rg) -> int {
+            int rcp;
+            // conv_0 + ReLU (+ AvgPool)
+            ConvGeom g0 = h->rconv[0].g;
+            set_spatial(g0, nb, sh.T, sh.F);
+            ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr, nullptr, rg};
+            if ((rcp = launch_layer(h->rconv[0], g0, a0, s, terms))) return rcp;
+            if (sh.pooled) HIP_TRY(launch_pool(bufA, X, nb * C, sh.T, sh.F, d.pool_h, d.pool_w, 0, s, rg));
+            // conv_i: odd i writes Y from X, even i accumulates into X from Y (prev_x lives in X)
+            for (int i = 1; i <= d.n_layers; ++i) {
+                ConvGeom g = h->rconv[i].g;
+                set_spatial(g, nb, sh.H, sh.W);
+                const bool even = (i % 2) == 0;
+                ConvArgs a{even ? Y : X, even ? X : Y, h->rconv[i].apk.as<float>(), nullptr, nullptr, nullptr,
+                           h->rconv[i].has_border ? h->rconv[i].border.as<float>() : nullptr, rg};
+                if ((rcp = launch_layer(h->rconv[i], g, a, s, terms))) return rcp;
+            }
+            const float* fin = (d.n_layers % 2 == 0) ? X : Y;
+            HIP_TRY(launch_mean_linear(fin, logits + (size_t)b0 * d.n_labels, nb, C, sh.H * sh.W,
+                                       h->bn_mean.as<float>() + (size_t)(d.n_layers - 1) * C,
+                                       h->bn_rstd.as<float>() + (size_t)(d.n_layers - 1) * C, h->out_w.as<float>(),
+                                       h->out_b.as<float>(), d.n_labels, s, rg));
+            return KWS_OK;
+        };
+        if ((rc = run_guarded(h, dtype_terms(d.dtype), s, pass))) return rc;
     }
     return KWS_OK;
 }
@@ -690,7 +735,7 @@ int launch_conv_auto(const ConvLayer& L, ConvGeom g, ConvArgs a, int nb, float* 
             a.partial = partial;
             int rc = launch_layer(L, g, a, s, terms);
             if (rc) return rc;
-            HIP_TRY(launch_splitk_reduce(partial, a.out, a.bias, g.ksplit, total, g.Cout, g.Ho * g.Wo, g.relu, s));
+            HIP_TRY(launch_splitk_reduce(partial, a.out, a.bias, g.ksplit, total, g.Cout, g.Ho * g.Wo, g.relu, s, a.rg));
             return KWS_OK;
         }
     }
@@ -705,44 +750,50 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
     float* P = (float*)ws;
     float* Q = (float*)(ws + align256(h->cnn_max_elems * cb * 4));
     float* part = (float*)(ws + 2 * align256(h->cnn_max_elems * cb * 4));
-    const int terms = dtype_terms(d.dtype);
     const size_t part_bytes = cnn_partial_bytes(h, cb);
     auto other = [&](const float* c) -> float* { return c == P ? Q : P; };
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
-        const float* cur = feat + (size_t)b0 * d.time * d.freq;
-        for (int i = 0; i < d.n_conv; ++i) {
-            ConvGeom g = h->cconv[i].g;
-            g.B = nb;
-            float* conv_out_buf = other(cur);
-            ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), nullptr, h->cconv[i].bias.as<float>(), nullptr, nullptr};
-            const int members = d.pool_kh[i] * d.pool_kw[i];
-            // MaxPool windows are reduced in the conv's accumulators (bf16x6 kernel, up to four members per pass over K);
-            // 1 x 1 pools (every pool_1 of the shipped configs) are the identity
-            if (h->cconv[i].use_x && members >= 2 && members <= 16) {
-                g.pool_h = d.pool_kh[i];
-                g.pool_w = d.pool_kw[i];
+        auto pass = [&](int terms, RangeGate rg) -> int {
+            const float* cur = feat + (size_t)b0 * d.time * d.freq;
+            // the feature maps come from the caller: the first pass checks them like any stored activation
+            if (rg.flag && !rg.gated) HIP_TRY(launch_range_check(cur, (long long)nb * d.time * d.freq, s, rg));
+            for (int i = 0; i < d.n_conv; ++i) {
+                ConvGeom g = h->cconv[i].g;
+                g.B = nb;
+                float* conv_out_buf = other(cur);
+                ConvArgs a{cur, conv_out_buf, h->cconv[i].apk.as<float>(), nullptr, h->cconv[i].bias.as<float>(), nullptr, nullptr, rg};
+                const int members = d.pool_kh[i] * d.pool_kw[i];
+                // MaxPool windows are reduced in the conv's accumulators (bf16x6 kernel, up to four members per pass over K);
+                // 1 x 1 pools (every pool_1 of the shipped configs) are the identity
+                if (h->cconv[i].use_x && members >= 2 && members <= 16) {
+                    g.pool_h = d.pool_kh[i];
+                    g.pool_w = d.pool_kw[i];
+                }
+                int rcc = launch_layer(h->cconv[i], g, a, s, terms);
+                if (rcc) return rcc;
+                if (g.pool_h || members == 1) {
+                    cur = conv_out_buf;
+                    continue;
+                }
+                float* pooled = other(conv_out_buf);
+                HIP_TRY(launch_pool(conv_out_buf, pooled, nb * g.Cout, g.Ho, g.Wo, d.pool_kh[i], d.pool_kw[i], 1, s, rg));
+                cur = pooled;
             }
-            int rcc = launch_layer(h->cconv[i], g, a, s, terms);
-            if (rcc) return rcc;
-            if (g.pool_h || members == 1) {
-                cur = conv_out_buf;
-                continue;
+            for (size_t i = 0; i < h->clin.size(); ++i) {
+                ConvGeom g = h->clin[i].g;
+                g.B = nb;
+                const bool last = i + 1 == h->clin.size();
+                float* dst = last ? logits + (size_t)b0 * d.n_labels : other(cur);
+                ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), nullptr, h->clin[i].bias.as<float>(), nullptr, nullptr, rg};
+                int rcl = launch_conv_auto(h->clin[i], g, a, nb, part, part_bytes, s, terms);
+                if (rcl) return rcl;
+                cur = dst;
             }
-            float* pooled = other(conv_out_buf);
-            HIP_TRY(launch_pool(conv_out_buf, pooled, nb * g.Cout, g.Ho, g.Wo, d.pool_kh[i], d.pool_kw[i], 1, s));
-            cur = pooled;
-        }
-        for (size_t i = 0; i < h->clin.size(); ++i) {
-            ConvGeom g = h->clin[i].g;
-            g.B = nb;
-            const bool last = i + 1 == h->clin.size();
-            float* dst = last ? logits + (size_t)b0 * d.n_labels : other(cur);
-            ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), nullptr, h->clin[i].bias.as<float>(), nullptr, nullptr};
-            int rc = launch_conv_auto(h->clin[i], g, a, nb, part, part_bytes, s, terms);
-            if (rc) return rc;
-            cur = dst;
-        }
+            return KWS_OK;
+        };
+        int rc = run_guarded(h, dtype_terms(d.dtype), s, pass);
+        if (rc) return rc;
     }
     return KWS_OK;
 }
@@ -835,6 +886,8 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
     }
     int rc = setup_frontend(h.get());
     if (rc) return rc;
+    const unsigned zero_word[64] = {0};
+    if ((rc = h->range_flag.upload(zero_word, sizeof(zero_word)))) return rc;
     switch (desc->family) {
         case KWS_MODEL_NONE: h->plan = PLAN_FRONTEND_ONLY; break;
         case KWS_MODEL_RESNET: h->plan = PLAN_RESNET; rc = build_resnet(h.get()); break;
@@ -849,6 +902,7 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
 void kws_destroy(kws_handle* h) { delete h; }
 
 int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, size_t bytes) {
+    DeviceGuard dg(h);
     if (!h || !host_ptr) return fail(KWS_EINVAL, "null argument");
     std::string name;
     int rc = strip_and_match(name_in, name);
@@ -939,6 +993,7 @@ size_t kws_workspace_bytes(const kws_handle* h, int B, int T) {
 }
 
 int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes) {
+    DeviceGuard dg(h);
     if (!h) return fail(KWS_EINVAL, "null handle");
     if (d_ptr && (reinterpret_cast<uintptr_t>(d_ptr) & 255)) return fail(KWS_EINVAL, "workspace must be 256-byte aligned");
     h->ws = d_ptr;
@@ -954,6 +1009,7 @@ int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes) {
 
 static int mfcc_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, const float* d_noise, float noise_pct,
                     int B, int n_samples, float* d_feat, void* stream, long long clip_stride = -1) {
+    DeviceGuard dg(h);
     if (!h || (!d_wav && !d_pcm) || !d_feat || B < 0) return fail(KWS_EINVAL, "bad argument");
     if (n_samples <= FE_NFFT / 2) return fail(KWS_EINVAL, "clip shorter than the reflect padding (n_fft/2 + 1 samples needed)");
     if (h->d.n_mels != h->d.freq && h->plan != PLAN_FRONTEND_ONLY) return fail(KWS_EINVAL, "n_mels != model frequency bins");
@@ -989,6 +1045,7 @@ int kws_mfcc_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise, fl
 }
 
 int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits, void* stream) {
+    DeviceGuard dg(h);
     if (!h || !d_feat || !d_logits || B < 0 || T < 1) return fail(KWS_EINVAL, "bad argument");
     int rc = finalize(h);
     if (rc) return rc;
@@ -1003,6 +1060,7 @@ int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits,
 
 static int forward_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, const float* d_noise, float noise_pct,
                        int B, int n_samples, float* d_logits, void* stream, long long clip_stride = -1) {
+    DeviceGuard dg(h);
     if (!h || (!d_wav && !d_pcm) || !d_logits || B < 0) return fail(KWS_EINVAL, "bad argument");
     int rc = finalize(h);
     if (rc) return rc;
@@ -1046,6 +1104,7 @@ static size_t global_feat_bytes(const kws_handle* h, int window, int shift, int 
 // features of all windows; gbuf: device scratch of global_feat_bytes() for the shared-frame path, or nullptr
 static int mfcc_windows_impl(kws_handle* h, const float* d_stream, int window, int shift, int n_windows, float* d_feat,
                              void* stream, float* gbuf) {
+    DeviceGuard dg(h);
     const bool no_share = std::getenv("KWS_WINDOWS_NO_SHARE") != nullptr;   // A/B and tests (read per call on purpose)
     if (!gbuf || no_share || !windows_share_frames(window, shift, n_windows))
         return mfcc_any(h, d_stream, nullptr, nullptr, 0.f, n_windows, window, d_feat, stream, shift);
@@ -1068,6 +1127,7 @@ size_t kws_workspace_bytes_windows(const kws_handle* h, int window, int shift, i
 
 int kws_mfcc_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
                      float* d_feat, void* stream) {
+    DeviceGuard dg(h);
     if (!h) return fail(KWS_EINVAL, "null handle");
     int rc = check_windows(n_stream, window, shift, n_windows);
     if (rc) return rc;
@@ -1078,6 +1138,7 @@ int kws_mfcc_windows(kws_handle* h, const float* d_stream, size_t n_stream, int 
 
 int kws_forward_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
                         float* d_logits, void* stream) {
+    DeviceGuard dg(h);
     if (!h || !d_stream || !d_logits) return fail(KWS_EINVAL, "bad argument");
     int rc = check_windows(n_stream, window, shift, n_windows);
     if (rc) return rc;
@@ -1095,6 +1156,7 @@ int kws_forward_windows(kws_handle* h, const float* d_stream, size_t n_stream, i
 
 int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target, int B, int64_t* d_stats,
                    double* d_loss_sum, void* stream) {
+    DeviceGuard dg(h);
     if (!h || !d_logits || !d_target || !d_stats || !d_loss_sum || B < 0) return fail(KWS_EINVAL, "bad argument");
     HIP_TRY(launch_eval_tail(d_logits, d_target, B, h->d.n_labels, d_stats, d_loss_sum, static_cast<hipStream_t>(stream)));
     return KWS_OK;
@@ -1103,12 +1165,19 @@ int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target
 const char* kws_plan_name(const kws_handle* h) { return h ? h->last_plan : "none"; }
 
 int kws_profile_enable(kws_handle* h, int enable) {
+    DeviceGuard dg(h);
     if (!h) return fail(KWS_EINVAL, "null handle");
     h->prof = enable != 0;
+    while (h->prof && h->ev_pool.size() < 4 * 128) {   // four events per wav -> logits call: 128 calls between two reads
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->ev_pool.push_back(e);
+    }
     return KWS_OK;
 }
 
 int kws_profile_read(kws_handle* h, double* model_ms, double* frontend_ms, int* calls) {
+    DeviceGuard dg(h);
     if (!h) return fail(KWS_EINVAL, "null handle");
     auto drain = [&](std::vector<hipEvent_t>& v, double& acc) -> int {
         for (size_t i = 0; i + 1 < v.size(); i += 2) {
@@ -1117,7 +1186,6 @@ int kws_profile_read(kws_handle* h, double* model_ms, double* frontend_ms, int* 
             HIP_TRY(hipEventElapsedTime(&ms, v[i], v[i + 1]));
             acc += ms;
         }
-        for (auto e : v) (void)hipEventDestroy(e);
         v.clear();
         return KWS_OK;
     };
@@ -1128,6 +1196,7 @@ int kws_profile_read(kws_handle* h, double* model_ms, double* frontend_ms, int* 
     if (model_ms) *model_ms = h->acc_model_ms;
     if (frontend_ms) *frontend_ms = h->acc_front_ms;
     if (calls) *calls = ncalls;
+    h->ev_next = 0;
     h->acc_model_ms = h->acc_front_ms = 0;
     return KWS_OK;
 }

@@ -74,6 +74,27 @@ struct DeviceOnce {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// ---------------------------------------------------------------- fp16 range guard of the layer-wise plans
+// The fp32-accurate default splits activations into two fp16 parts, which cannot hold |x| > 65 504 (the reference is fp32
+// throughout, model/resnet.py:38-60, model/cnn.py:79-107).  Every kernel that STORES an activation another kernel will
+// split notes the largest magnitude it wrote: at or above KWS_RANGE_LIMIT it sets one device word (an
+// infinity is caught as such, before it can turn into a NaN).  After the
+// chunk's fp16 pass the same plan is launched again on three-part bf16 operands (fp32's exponent range, six terms) with
+// `gated` = 1: those kernels return at once unless the word is set.  No host round trip; trained models never trip it.
+struct RangeGate {
+    unsigned* flag;   // device word (zeroed before the chunk's first pass), or nullptr: no guard
+    int gated;        // 0: note what is stored; 1: run only if *flag != 0
+};
+constexpr float KWS_RANGE_LIMIT = 32768.f;
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool range_gate_closed(const RangeGate& rg) {
+    return rg.gated && rg.flag && __builtin_nontemporal_load(rg.flag) == 0u;
+}
+__device__ __forceinline__ void range_note(const RangeGate& rg, float amax) {
+    if (!rg.gated && rg.flag && amax >= KWS_RANGE_LIMIT) *rg.flag = 1u;   // same value from every writer: a benign race
+}
+#endif
+
 // ---------------------------------------------------------------- front end (frontend.hip)
 constexpr int FE_NFFT = 480;
 constexpr int FE_HOP = 160;
@@ -229,6 +250,7 @@ struct ConvArgs {
     const float* bias;     // (Cout) or nullptr
     float* partial;        // (ksplit, B, Cout, Ho*Wo) raw partial sums when ksplit > 1 (then reduced by launch_splitk_reduce)
     const float* border;   // (16, Cout) or nullptr: previous layer's BN shift summed over the in-bounds taps, by border class
+    RangeGate rg;          // fp16 range guard (zero-initialised: none)
 };
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, hipStream_t s);
 void pack_conv_weights(const ConvGeom& g, const float* w /*Cout,Cin,kh,kw*/, std::vector<float>& dst);
@@ -256,24 +278,29 @@ struct TileConvParams {
     int terms;             // bf16 parts only: 6 / 3 / 1 terms per product
     int f16;               // 1: two-part fp16 operands, three terms (fp32-accurate default)
     float inv_scale;       // 2^-S of the fp16 weights (1 for bf16)
+    RangeGate rg;          // fp16 range guard (zero-initialised: none)
 };
 bool conv3x3_tile_supported(int C, int Cout, int Ws);
 void pack_conv3x3_tile_weights_f16(int C, const float* w /*C,C,3,3*/, float scale, std::vector<unsigned short>& dst);
 hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
 // fp32 (B, C, H, W) -> pooled (stride = window, floor; 1 x 1 = transpose only) channels-last (B, H/kh, W/kw, cp) fp32
 hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, int W, int kh, int kw, int is_max, int cp,
-                             hipStream_t s);
+                             hipStream_t s, RangeGate rg = RangeGate{nullptr, 0});
 hipError_t launch_mean_linear_cl(const float* x, float* logits, int B, int C, int cp, int HW, const float* mean,
-                                 const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s);
+                                 const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s,
+                                 RangeGate rg = RangeGate{nullptr, 0});
 // out[i] = (relu?)(bias[co] + sum_z partial[z][i]) for i over (B, Cout, npc)
 hipError_t launch_splitk_reduce(const float* partial, float* out, const float* bias, int ksplit, long long total,
-                                int Cout, int npc, int relu, hipStream_t s);
+                                int Cout, int npc, int relu, hipStream_t s, RangeGate rg = RangeGate{nullptr, 0});
 
 hipError_t launch_pool(const float* in, float* out, int planes /*B*C*/, int H, int W, int kh, int kw, int is_max,
-                       hipStream_t s);
+                       hipStream_t s, RangeGate rg = RangeGate{nullptr, 0});
+// sets *rg.flag when x holds a value the fp16 parts cannot carry (the caller-provided features of a CNN)
+hipError_t launch_range_check(const float* x, long long n, hipStream_t s, RangeGate rg);
 // logits[b] = W * ((mean_hw(x[b]) - mean) * rstd) + bias     (mean/rstd may be nullptr = identity)
 hipError_t launch_mean_linear(const float* x, float* logits, int B, int C, int HW, const float* mean,
-                              const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s);
+                              const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s,
+                              RangeGate rg = RangeGate{nullptr, 0});
 hipError_t launch_eval_tail(const float* logits, const int64_t* target, int B, int n_labels, int64_t* stats,
                             double* loss_sum, hipStream_t s);
 

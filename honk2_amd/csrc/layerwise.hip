@@ -21,6 +21,8 @@
 //   Activations are fp32 (B, C, H, W) in the caller-provided workspace.
 #include "kws_internal.h"
 
+#include <algorithm>
+
 namespace kws {
 
 namespace {
@@ -32,6 +34,7 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int s
 
 template <int MT, bool KX>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a) {
+    if (range_gate_closed(a.rg)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a
                    (ix0[j] + 2 * gm.dw < gm.W ? 8 : 0);
 
     // epilogue: D[row = 4g + r][col = pcol]; rows are output channels
+    float amax = 0.f;   // largest magnitude stored (fp16 range guard)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -196,8 +200,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvGeom gm, ConvArgs a
                 const size_t idx = ((size_t)bidx[j] * gm.Cout + co) * npc + pos[j];
                 if (gm.accumulate) v += a.out[idx];
                 a.out[idx] = v;
+                amax = fmaxf(amax, fabsf(v));
             }
         }
+    range_note(a.rg, amax);
 }
 
 int choose_mt(int mtiles) {
@@ -265,19 +271,22 @@ void pack_conv_weights(const ConvGeom& g, const float* w, std::vector<float>& ds
 // ------------------------------------------------------------------------------------------------ split-K reduce
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                             const float* __restrict__ bias, int ksplit, long long total,
-                                                            int Cout, int npc, int relu) {
+                                                            int Cout, int npc, int relu, RangeGate rg) {
+    if (range_gate_closed(rg)) return;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     float v = bias ? bias[(int)((i / npc) % Cout)] : 0.f;
     for (int z = 0; z < ksplit; ++z) v += partial[(size_t)z * total + i];   // fixed order: deterministic
-    out[i] = relu ? fmaxf(v, 0.f) : v;
+    v = relu ? fmaxf(v, 0.f) : v;
+    out[i] = v;
+    range_note(rg, fabsf(v));
 }
 
 hipError_t launch_splitk_reduce(const float* partial, float* out, const float* bias, int ksplit, long long total,
-                                int Cout, int npc, int relu, hipStream_t s) {
+                                int Cout, int npc, int relu, hipStream_t s, RangeGate rg) {
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, out, bias,
-                       ksplit, total, Cout, npc, relu);
+                       ksplit, total, Cout, npc, relu, rg);
     return hipGetLastError();
 }
 
@@ -285,7 +294,8 @@ hipError_t launch_splitk_reduce(const float* partial, float* out, const float* b
 // AvgPool2d / MaxPool2d with stride == kernel, floor mode (reference model/resnet.py:34, model/cnn.py:30,43).
 __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                    long long total, int H, int W, int Ho, int Wo, int kh, int kw,
-                                                   int is_max) {
+                                                   int is_max, RangeGate rg) {
+    if (range_gate_closed(rg)) return;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int ox = (int)(i % Wo);
@@ -299,16 +309,35 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ in,
             const float s = src[y * W + x];
             v = is_max ? fmaxf(v, s) : v + s;
         }
-    out[i] = is_max ? v : v / (float)(kh * kw);
+    v = is_max ? v : v / (float)(kh * kw);
+    out[i] = v;
+    range_note(rg, fabsf(v));
+}
+
+// fp16 range guard for tensors the library does not produce itself (the feature maps handed to a CNN)
+__global__ __launch_bounds__(256) void range_check_kernel(const float* __restrict__ x, long long n, RangeGate rg) {
+    float amax = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        amax = fmaxf(amax, fabsf(v));
+    }
+    range_note(rg, amax);
+}
+
+hipError_t launch_range_check(const float* x, long long n, hipStream_t s, RangeGate rg) {
+    if (n <= 0 || !rg.flag) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(range_check_kernel, dim3(grid), dim3(256), 0, s, x, n, rg);
+    return hipGetLastError();
 }
 
 hipError_t launch_pool(const float* in, float* out, int planes, int H, int W, int kh, int kw, int is_max,
-                       hipStream_t s) {
+                       hipStream_t s, RangeGate rg) {
     const int Ho = H / kh, Wo = W / kw;
     const long long total = (long long)planes * Ho * Wo;
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, H, W, Ho,
-                       Wo, kh, kw, is_max);
+                       Wo, kh, kw, is_max, rg);
     return hipGetLastError();
 }
 
@@ -317,8 +346,9 @@ hipError_t launch_pool(const float* in, float* out, int planes, int H, int W, in
 __global__ __launch_bounds__(256) void mean_linear_kernel(const float* __restrict__ x, float* __restrict__ logits,
                                                           int C, int HW, const float* mean, const float* rstd,
                                                           const float* __restrict__ wt, const float* __restrict__ bias,
-                                                          int n_out) {
+                                                          int n_out, RangeGate rg) {
     extern __shared__ float mv[];
+    if (range_gate_closed(rg)) return;
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -343,16 +373,19 @@ __global__ __launch_bounds__(256) void mean_linear_kernel(const float* __restric
 }
 
 hipError_t launch_mean_linear(const float* x, float* logits, int B, int C, int HW, const float* mean,
-                              const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s) {
+                              const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s, RangeGate rg) {
     if (B <= 0) return hipSuccess;
     hipLaunchKernelGGL(mean_linear_kernel, dim3((unsigned)B), dim3(256), (size_t)C * sizeof(float), s, x, logits, C,
-                       HW, mean, rstd, w, bias, n_out);
+                       HW, mean, rstd, w, bias, n_out, rg);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ evaluation tail
 // ce_loss (loss_function.py:6-9) + Acc.accumulate (metric/acc.py:14-24) + PerClassAcc.accumulate
-// (metric/per_class_acc.py:14-45) in one pass: stats = [correct, total, per-class correct[n], per-class total[n]].
+// (metric/per_class_acc.py:14-45) in one pass: stats = [correct, total, per-class correct[n], per-class total[n], bad].
+// A target outside [0, n) (the reference's F.cross_entropy raises on one) is never used as an index: the clip is skipped
+// and counted in stats[2 + 2n], which the caller checks after its one device-to-host copy.  NaN logits take the argmax
+// as in torch.argmax (the first NaN wins).
 __global__ __launch_bounds__(256) void eval_tail_kernel(const float* __restrict__ logits,
                                                         const int64_t* __restrict__ target, int B, int n,
                                                         unsigned long long* stats, double* loss_sum) {
@@ -360,23 +393,28 @@ __global__ __launch_bounds__(256) void eval_tail_kernel(const float* __restrict_
     double loss = 0.0;
     if (b < B) {
         const float* z = logits + (size_t)b * n;
-        int arg = 0;
-        float zmax = z[0];
-        for (int i = 1; i < n; ++i)
-            if (z[i] > zmax) {   // first maximum wins, as torch.argmax
-                zmax = z[i];
-                arg = i;
+        const int64_t t64 = target[b];
+        if (t64 < 0 || t64 >= (int64_t)n) {
+            atomicAdd(&stats[2 + 2 * n], 1ull);
+        } else {
+            const int t = (int)t64;
+            int arg = 0;
+            float zmax = z[0];
+            for (int i = 1; i < n; ++i)
+                if (z[i] > zmax || (z[i] != z[i] && zmax == zmax)) {   // first maximum wins, NaN counts as the maximum
+                    zmax = z[i];
+                    arg = i;
+                }
+            double se = 0.0;
+            for (int i = 0; i < n; ++i) se += exp((double)z[i] - (double)zmax);
+            loss = log(se) - ((double)z[t] - (double)zmax);
+            const bool hit = arg == t;
+            atomicAdd(&stats[1], 1ull);
+            atomicAdd(&stats[2 + n + t], 1ull);
+            if (hit) {
+                atomicAdd(&stats[0], 1ull);
+                atomicAdd(&stats[2 + t], 1ull);
             }
-        double se = 0.0;
-        for (int i = 0; i < n; ++i) se += exp((double)z[i] - (double)zmax);
-        const int t = (int)target[b];
-        loss = log(se) - ((double)z[t] - (double)zmax);
-        const bool hit = arg == t;
-        atomicAdd(&stats[1], 1ull);
-        atomicAdd(&stats[2 + n + t], 1ull);
-        if (hit) {
-            atomicAdd(&stats[0], 1ull);
-            atomicAdd(&stats[2 + t], 1ull);
         }
     }
 #pragma unroll

@@ -98,6 +98,7 @@ __device__ __forceinline__ void split8_f16(const float (&x)[8], u32x4 (&out)[3])
 template <int MT, bool KX, int TERMS, bool MULTI, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvArgs a) {
     constexpr int LP = F16 ? 2 : 3;   // weight parts per fragment group
+    if (range_gate_closed(a.rg)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
         bmask[j] = (iy0[j] >= 0 ? 1 : 0) | (iy0[j] + 2 * gm.dh < gm.H ? 2 : 0) | (ix0[j] >= 0 ? 4 : 0) |
                    (ix0[j] + 2 * gm.dw < gm.W ? 8 : 0);
 
+    float amax = 0.f;   // largest magnitude stored (fp16 range guard; split-K partials are checked by the reduce kernel)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
                 v = fmaf(v, gm.x_inv_scale, bias);   // 2^-S > 0 commutes with the maximum
                 if (gm.relu) v = fmaxf(v, 0.f);
                 a.out[((size_t)bidx[0] * gm.Cout + co) * npc + pos[0]] = v;
+                amax = fmaxf(amax, fabsf(v));
                 continue;
             }
 #pragma unroll
@@ -296,8 +299,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
                 const size_t idx = ((size_t)bidx[j] * gm.Cout + co) * npc + pos[j];
                 if (gm.accumulate) v += a.out[idx];
                 a.out[idx] = v;
+                amax = fmaxf(amax, fabsf(v));
             }
         }
+    range_note(a.rg, amax);
 }
 
 template <int MT>

@@ -27,6 +27,7 @@ from ..utils import AudioProcessor, register_cls
 @register_cls('data_loader.AudioDataLoader')
 class AudioDataLoader(DataLoader):
     def __init__(self, data_loader_config, dataset):
+        self.config = dict(data_loader_config)        # kept so that a sharded evaluation can rebuild the same loader
         self.audio_preprocessing = data_loader_config["audio_preprocessing"]
         if self.audio_preprocessing != "MFCCs":
             raise ValueError(f"audio_preprocessing={self.audio_preprocessing!r}: only 'MFCCs' is supported "

@@ -72,8 +72,13 @@ class BaseModel(ABC, nn.Module):
 
     def engine(self):
         """The kws_handle for this model with the current weights loaded (re-uploaded when they change)."""
+        device = next(self.parameters()).device          # the engine lives where the model's tensors live
+        if self._engine is not None and device.type == "cuda" and self._engine.device != (
+                device if device.index is not None else torch.device("cuda", torch.cuda.current_device())):
+            self._engine.close()                          # the model was moved to another GPU after its first use
+            self._engine = None
         if self._engine is None:
-            self._engine = _lib.Engine(self._make_desc())
+            self._engine = _lib.Engine(self._make_desc(), device if device.type == "cuda" else None)
             self._engine_key = None
         key = self._weights_key()
         if key != self._engine_key:

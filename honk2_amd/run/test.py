@@ -34,6 +34,16 @@ def _fusable(device, model, loss_fn, metrics):
 
 
 def evaluate(device, prefix, model, data_loader, loss_fn, metrics, label_mapping, progress=True):
+    """Reference signature and result dict (``run/test.py:18-41``)."""
+    loss_sum, n_batches = evaluate_partial(device, prefix, model, data_loader, loss_fn, metrics, progress)
+    results = {"loss": loss_sum / n_batches}               # an empty loader divides by zero, as in the reference
+    results.update(collect_metrics(metrics, label_mapping))
+    return results
+
+
+def evaluate_partial(device, prefix, model, data_loader, loss_fn, metrics, progress=True):
+    """One pass over `data_loader`: accumulates into `metrics` and returns (sum of the per-batch mean losses, number of
+    batches) -- the two numbers a multi-rank evaluation has to add up before dividing once."""
     model.eval()
     batches = tqdm(data_loader, desc=f"Evaluating {prefix} dataset") if progress else data_loader
     if not _fusable(device, model, loss_fn, metrics):
@@ -45,15 +55,13 @@ def evaluate(device, prefix, model, data_loader, loss_fn, metrics, label_mapping
             total_loss += loss_fn(output, target).item()
             for metric in metrics.values():
                 metric.accumulate(output, target)
-        results = {"loss": total_loss / len(data_loader)}
-        results.update(collect_metrics(metrics, label_mapping))
-        return results
+        return total_loss, len(data_loader)
 
     inner = model.module if hasattr(model, "module") else model
     engine = inner.engine()
     n_labels = inner.config["n_labels"]
     n_batches = len(data_loader)
-    stats = torch.zeros(2 + 2 * n_labels, dtype=torch.int64, device=device)
+    stats = torch.zeros(3 + 2 * n_labels, dtype=torch.int64, device=device)
     loss_sums = torch.zeros(max(n_batches, 1), dtype=torch.float64, device=device)
     sizes = []
     for i, (data, target) in enumerate(batches):
@@ -64,15 +72,15 @@ def evaluate(device, prefix, model, data_loader, loss_fn, metrics, label_mapping
         sizes.append(output.shape[0])
     host_stats = stats.cpu().tolist()                      # the one synchronising copy
     host_loss = loss_sums.cpu().tolist()
+    if host_stats[2 + 2 * n_labels]:                       # the reference's F.cross_entropy raises on such a target
+        raise IndexError(f"{host_stats[2 + 2 * n_labels]} target(s) outside [0, {n_labels}) in the {prefix} dataset")
     per_batch = [s / b for s, b in zip(host_loss, sizes)]
-    results = {"loss": sum(per_batch) / len(data_loader)}
     for metric in metrics.values():
         if isinstance(metric, Acc):
             metric.add_counts(host_stats[0], host_stats[1])
         else:
             metric.add_counts(host_stats[2:2 + n_labels], host_stats[2 + n_labels:2 + 2 * n_labels])
-    results.update(collect_metrics(metrics, label_mapping))
-    return results
+    return sum(per_batch), len(data_loader)
 
 
 def build_model(config):
@@ -95,13 +103,8 @@ def main(config):
 
     test_data_loader = init_data_loader(config, DatasetType.TEST)
     label_mapping = test_data_loader.dataset.label_mapping
-    if world > 1:   # one contiguous shard per rank; weights are replicated by construction (same seed / checkpoint)
-        lo, hi = dist_utils.shard_bounds(len(test_data_loader.dataset), rank, world)
-        shard = torch.utils.data.Subset(test_data_loader.dataset, range(lo, hi))
-        shard.label_mapping = label_mapping
-        test_data_loader = type(test_data_loader)(
-            {"audio_preprocessing": test_data_loader.audio_preprocessing, "batch_size": test_data_loader.batch_size,
-             "num_workers": test_data_loader.num_workers}, shard)
+    if world > 1:
+        test_data_loader = shard_loader(test_data_loader, rank, world)
     if rank == 0:
         print(f"test dataset size: {len(test_data_loader.dataset)}" + (f" (per rank, {world} ranks)" if world > 1 else ""))
 
@@ -121,37 +124,55 @@ def main(config):
     elif rank == 0:
         print("no evaluate_model_dir in config: evaluating randomly initialised weights")
 
-    results = evaluate(device, "test", model, test_data_loader, loss_fn, metrics, label_mapping, progress=rank == 0)
     if world > 1:
-        results = reduce_results(results, metrics, label_mapping, device)
+        loss_sum, n_batches = evaluate_partial(device, "test", model, test_data_loader, loss_fn, metrics, progress=rank == 0)
+        results = reduce_results(loss_sum, n_batches, metrics, label_mapping, device)
+    else:
+        results = evaluate(device, "test", model, test_data_loader, loss_fn, metrics, label_mapping, progress=True)
     if rank == 0:
         print("Test results")
         pprint(results)
     return results
 
 
-def reduce_results(results, metrics, label_mapping, device):
-    """Combine per-rank counters (sum) and losses (mean over ranks) with one small all-reduce."""
+def shard_loader(loader, rank, world):
+    """Rank `rank`'s loader: a contiguous run of the single-process loader's BATCHES (so every batch, and with it every
+    per-batch mean loss, is the one the single-process evaluation sees), built from the same loader config.  A rank may
+    end up with no batch at all when the dataset has fewer batches than ranks."""
+    if getattr(loader, "_shuffled", False):
+        raise ValueError("sharded evaluation needs an unshuffled test loader")
+    n, bs = len(loader.dataset), loader.batch_size
+    lo_b, hi_b = dist_utils.shard_bounds((n + bs - 1) // bs, rank, world)
+    shard = torch.utils.data.Subset(loader.dataset, range(min(lo_b * bs, n), min(hi_b * bs, n)))
+    shard.label_mapping = loader.dataset.label_mapping
+    return type(loader)(dict(loader.config, shuffle=False), shard)
+
+
+def reduce_results(loss_sum, n_batches, metrics, label_mapping, device):
+    """One small all-reduce (sum) of [sum of per-batch mean losses, batches, counters]; the loss is divided ONCE by the
+    global number of batches, which reproduces the single-process ``total_loss / len(data_loader)`` for any split."""
     import torch.distributed as dist
     n = len(label_mapping)
-    buf = torch.zeros(3 + 2 * n, dtype=torch.float64, device=device)
-    buf[0] = results["loss"]
+    buf = torch.zeros(4 + 2 * n, dtype=torch.float64, device=device)
+    buf[0], buf[1] = loss_sum, n_batches
     for m in metrics.values():
         if isinstance(m, Acc):
-            buf[1], buf[2] = m.correct, m.total
+            buf[2], buf[3] = m.correct, m.total
         elif isinstance(m, PerClassAcc):
             for k, v in m.total.items():
-                buf[3 + k] = m.correct[k]
-                buf[3 + n + k] = v
+                buf[4 + k] = m.correct[k]
+                buf[4 + n + k] = v
     dist.all_reduce(buf)
     host = buf.cpu().tolist()
     for m in metrics.values():
         m.reset_metric()
         if isinstance(m, Acc):
-            m.add_counts(round(host[1]), round(host[2]))
+            m.add_counts(round(host[2]), round(host[3]))
         elif isinstance(m, PerClassAcc):
-            m.add_counts([round(x) for x in host[3:3 + n]], [round(x) for x in host[3 + n:3 + 2 * n]])
-    out = {"loss": host[0] / dist.get_world_size()}
+            m.add_counts([round(x) for x in host[4:4 + n]], [round(x) for x in host[4 + n:4 + 2 * n]])
+    if round(host[1]) == 0:
+        raise ZeroDivisionError("empty test dataset")
+    out = {"loss": host[0] / round(host[1])}
     out.update(collect_metrics(metrics, label_mapping))
     return out
 

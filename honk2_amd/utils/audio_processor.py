@@ -24,27 +24,32 @@ class AudioProcessor(object):
         self.f_min = f_min
         self.n_fft = n_fft
         self.hop_length = sr // 1000 * hop_ms
-        self._engine = None
+        self._engines = {}        # one front-end handle per GPU, created where the first tensor from that GPU arrives
 
-    def _get_engine(self):
-        if self._engine is None:
+    def _get_engine(self, like=None):
+        import torch
+        if isinstance(like, torch.Tensor) and like.is_cuda:
+            index = like.device.index
+        else:
+            index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        if index not in self._engines:
             desc = _lib.make_desc(_lib.KWS_MODEL_NONE, frontend=dict(
                 sample_rate=self.sr, n_fft=self.n_fft, hop_length=self.hop_length, n_mels=self.n_mels,
                 f_min=float(self.f_min), f_max=float(self.f_max)))
-            self._engine = _lib.Engine(desc)
-        return self._engine
+            self._engines[index] = _lib.Engine(desc, f"cuda:{index}" if torch.cuda.is_available() else None)
+        return self._engines[index]
 
     def num_frames(self, n_samples):
         return 1 + n_samples // self.hop_length
 
     def compute_mfccs_batch(self, wav, noise=None, noise_pct=0.0):
         """(B, n) float32 or int16-PCM tensor on the GPU -> (B, T, n_mels) float32 tensor on the GPU."""
-        return self._get_engine().mfcc(wav, noise, noise_pct)
+        return self._get_engine(wav).mfcc(wav, noise, noise_pct)
 
     def compute_mfccs_windows(self, stream, window, shift, first=0, count=None):
         """1-D float32 stream on the GPU -> features (count, T, n_mels) of the windows ``stream[i*shift : i*shift + window]``,
         ``i = first .. first + count - 1`` (the items of the reference's ``StreamingDataset``), read in place."""
-        return self._get_engine().mfcc_windows(stream, window, shift, first, count)
+        return self._get_engine(stream).mfcc_windows(stream, window, shift, first, count)
 
     def compute_mfccs(self, data):
         import torch

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define KWS_ABI_VERSION 1
+#define KWS_ABI_VERSION 2
 
 enum {
     KWS_OK = 0,
@@ -147,8 +147,11 @@ int kws_mfcc_windows(kws_handle* h, const float* d_stream, size_t n_stream, int 
 int kws_forward_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
                         float* d_logits, void* stream);
 
-/* Evaluation tail, fused: adds to d_stats (int64[2 + 2*n_labels] = correct, total, per-class correct[n],
- * per-class total[n]) and to d_loss_sum (double[1]: sum over clips of the cross-entropy, natural log). */
+/* Evaluation tail, fused: adds to d_stats (int64[3 + 2*n_labels] = correct, total, per-class correct[n],
+ * per-class total[n], clips skipped because their target lies outside [0, n_labels)) and to d_loss_sum (double[1]: sum
+ * over the counted clips of the cross-entropy, natural log).  A bad target is never used as an index; the caller reads
+ * the last counter after its device-to-host copy and treats a non-zero value as the error the reference's
+ * F.cross_entropy raises (loss_function.py:6-9). */
 int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target, int B,
                    int64_t* d_stats, double* d_loss_sum, void* stream);
 

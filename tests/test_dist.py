@@ -47,22 +47,34 @@ def _worker(rank, world, port, total, out_dir):
     counts = [b - a for a, b in (dist_utils.shard_bounds(total, i, world) for i in range(world))]
     gathered = dist_utils.all_gather_rows(logits[lo:hi].clone(), counts if len(set(counts)) > 1 else None)
     assert torch.equal(gathered, logits)                       # rank order == clip order
+    # evaluation: rank r owns a contiguous run of the single-process loader's BATCHES (run/test.py:shard_loader); the
+    # reduced loss must be the single-process mean of per-batch means for uneven splits, ragged last batches and
+    # ranks that own no batch at all
+    import torch.nn.functional as F
+    bs = 8
+    nb = (total + bs - 1) // bs
+    lo_b, hi_b = dist_utils.shard_bounds(nb, rank, world)
     acc, pca = Acc(), PerClassAcc()
-    acc.accumulate(logits[lo:hi], target[lo:hi])
-    pca.accumulate(logits[lo:hi], target[lo:hi])
-    res = reduce_results({"loss": float(rank)}, {"Acc": acc, "PerClassAcc": pca},
+    loss_sum = 0.0
+    for i in range(lo_b, hi_b):
+        o, t = logits[i * bs:(i + 1) * bs], target[i * bs:(i + 1) * bs]
+        loss_sum += F.cross_entropy(o, t).item()
+        acc.accumulate(o, t)
+        pca.accumulate(o, t)
+    res = reduce_results(loss_sum, hi_b - lo_b, {"Acc": acc, "PerClassAcc": pca},
                          {i: f"c{i}" for i in range(12)}, torch.device("cpu"))
     ref_a, ref_p = Acc(), PerClassAcc()
     ref_a.accumulate(logits, target)
     ref_p.accumulate(logits, target)
     assert res["metric_Acc"] == ref_a.get_metric()
     assert res["metric_PerClassAcc"] == {f"c{k}": v for k, v in ref_p.get_metric().items()}
-    assert abs(res["loss"] - (world - 1) / 2) < 1e-12          # mean over ranks
+    ref_loss = sum(F.cross_entropy(logits[i * bs:(i + 1) * bs], target[i * bs:(i + 1) * bs]).item() for i in range(nb)) / nb
+    assert abs(res["loss"] - ref_loss) < 1e-12
     np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.ones(1))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [64, 37])
+@pytest.mark.parametrize("total", [64, 37, 5])
 def test_two_rank_gather_and_reduce(tmp_path, total):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)

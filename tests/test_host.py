@@ -89,7 +89,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol(lib_built):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for sym in declared:
         assert hasattr(lib_built, sym), sym
-    assert lib_built.kws_abi_version() == 1
+    assert lib_built.kws_abi_version() == 2
     assert ctypes.sizeof(_lib.ModelDesc) == 4 * (11 + 1 + 10 + 4 + 3 + 4) + 8
     # without a GPU kws_create must fail loudly, not fall back
     if not torch.cuda.is_available():
