@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkws_hip.so")
+# KWS_LIB points experiments (A/B builds of one kernel) at another build of the same library; default = the in-tree build
+LIB_PATH = os.environ.get("KWS_LIB") or os.path.join(_HERE, "libkws_hip.so")
 
 KWS_MODEL_NONE, KWS_MODEL_RESNET, KWS_MODEL_CNN = 0, 1, 2
 KWS_DTYPE_F32, KWS_DTYPE_BF16X3, KWS_DTYPE_BF16, KWS_DTYPE_F16 = 0, 1, 2, 3

@@ -812,6 +812,7 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 for (int i = 0; i < R8_LAYERS; ++i) p.inv_scale[i] = 1.0f / h->r8h_scale[i];
                 p.B = B; p.T = T; p.F = h->d.freq; p.n_labels = h->d.n_labels; p.debug = dbg;
                 p.terms = h->d.dtype == KWS_DTYPE_F16 ? 1 : 3;
+                p.queue = h->range_flag.as<unsigned>() + 16;   // (word 0 of that block is the layer-wise range flag)
                 static const int r8_wgs = std::getenv("KWS_R8_WGS_PER_CU") ? std::atoi(std::getenv("KWS_R8_WGS_PER_CU")) : 2;
                 HIP_TRY(launch_res8h(p, std::min(B, r8_wgs * h->n_cu), s));
             } else if (h->res8_impl == 2) {

@@ -212,6 +212,7 @@ struct Res8hParams {
     int B, T, F, n_labels;
     int debug;            // timing experiments only: 1 skip conv_0, 2 skip the MFMA loop
     int terms;            // 3: fp32-accurate products; 1: plain fp16 operands (KWS_DTYPE_F16)
+    unsigned* queue;      // device word: next clip to hand out (launch_res8h sets it to the grid size)
 };
 size_t res8h_lds_bytes();
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s);

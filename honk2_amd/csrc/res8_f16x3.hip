@@ -47,7 +47,8 @@ constexpr int FEAT_BYTES = ((102 * FS * 4 + 15) / 16) * 16;
 static_assert(FEAT_BYTES <= MAP_BYTES, "the feature map is staged inside the (idle) activation map");
 constexpr int RED_OFF = MAP_BYTES;                    // fp32 words from here on
 constexpr int BNT_WORDS = R8_LAYERS * 96;
-constexpr int X_LDS_BYTES = RED_OFF + (4 * 48 + 48 + BNT_WORDS) * 4;
+constexpr int NEXT_OFF = RED_OFF + (4 * 48 + 48 + BNT_WORDS) * 4;   // one word: the clip this workgroup takes next
+constexpr int X_LDS_BYTES = NEXT_OFF + 16;
 constexpr int KSTEPS = R8X_KSTEPS;                    // 14
 constexpr int A_STEP = 3 * 2 * 64;                    // u32x4 per k-step: [channel tile][part][lane]
 
@@ -60,16 +61,23 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     const f16x2 v = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(unsigned, v);
 }
-__device__ __forceinline__ float lo_f(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
-__device__ __forceinline__ float hi_f(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
 
+// second fp16 parts of (a, b) given their packed first parts h: fp16(a - float(h.lo)), fp16(b - float(h.hi)).  The
+// difference is exact in fp32, so one mixed-precision FMA per value (f16 source, f32 addend, f16 result) gives the same
+// bits as convert-back, subtract, convert (which costs three instructions per value).
+__device__ __forceinline__ unsigned resid2(unsigned h, float a, float b) {
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+    return l;
+}
 // split 4 consecutive channels into two fp16 parts and store them at byte address `addr` (+ part * 96)
 __device__ __forceinline__ void store_split(char* lds, int addr, f32x4 v) {
     u32x2 h, m;
     h[0] = pack2(v[0], v[1]);
     h[1] = pack2(v[2], v[3]);
-    m[0] = pack2(v[0] - lo_f(h[0]), v[1] - hi_f(h[0]));
-    m[1] = pack2(v[2] - lo_f(h[1]), v[3] - hi_f(h[1]));
+    m[0] = resid2(h[0], v[0], v[1]);
+    m[1] = resid2(h[1], v[2], v[3]);
     *reinterpret_cast<u32x2*>(lds + addr) = h;
     *reinterpret_cast<u32x2*>(lds + addr + PART_B) = m;
 }
@@ -178,9 +186,20 @@ __device__ __forceinline__ void load_b(BFrag& b, const char* lds, int a0, int a1
         }                                                                             \
     }
 
+// A/B knobs of this file (defaults = what measured best):
+//   R8H_PRIO      wave priority inside the k-loops (s_setprio; the matrix stream of one workgroup against the vector-heavy
+//                 phases of the other workgroup on the same SIMD)
+//   R8H_PREFETCH  the first weight fragments of layer i + 1 are requested before layer i's epilogue and barriers
+#ifndef R8H_PRIO
+#define R8H_PRIO 0
+#endif
+#ifndef R8H_PREFETCH
+#define R8H_PREFETCH 1
+#endif
+
 template <int TERMS, bool EVEN, bool LAST>
 __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int layer, int clip, f32x4 (&prev)[5][3],
-                                        f32x4& prevx, int& shift) {
+                                        f32x4& prevx, int& shift, AFrags& fa0) {
     const int g = c.g, mx = c.mx;
     f32x4 acc[5][3], accx;
 #pragma unroll
@@ -190,9 +209,10 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
     accx = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const u32x4* A = reinterpret_cast<const u32x4*>(p.apk2) + (size_t)layer * R8H_ASTEPS * A_STEP + c.lane;
-    AFrags fa0, fa1;
+    AFrags fa1;
     BFrag bb0, bb1;   // ping-pong over position tiles; 6 tiles per step keeps the parity aligned across steps
-    load_a(fa0, A, 0, mx);
+    if (!R8H_PREFETCH) load_a(fa0, A, 0, mx);   // otherwise requested by the previous layer (or by the clip prologue)
+    if (R8H_PRIO) __builtin_amdgcn_s_setprio(R8H_PRIO);
     load_b(bb0, c.lds, c.qb[0] + step_boff(0, g), c.qb[0] + step_boff(0, g) + PART_B);
 #define MFS0(M, B, C) MF6(fa0.a[M], B, C)
 #define MFS1(M, B, C) MF6(fa1.a[M], B, C)
@@ -234,6 +254,12 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
 #undef X_PAIR
 #undef MFS0
 #undef MFS1
+    if (R8H_PRIO) __builtin_amdgcn_s_setprio(0);
+    if (R8H_PREFETCH && !LAST) {   // next layer's first fragments: in flight across this layer's epilogue and barriers
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(fa0, A + (size_t)R8H_ASTEPS * A_STEP, 0, mx);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ---- epilogue in fp32: ReLU, residual (reference: even i), BatchNorm as one FMA.  The accumulators carry the layer's
     //      weight scale 2^S; 2^-S rides on the residual FMA (even layers) or is already folded into the BatchNorm scale of
@@ -242,10 +268,13 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
     const float up = shift > 0 ? ldexpf(1.f, shift) : 1.f;   // undo the range guard of the map this layer read (uniform)
     const float inv = p.inv_scale[layer] * up;
     float amax = 0.f;
+    // (odd layers: the power of two that undoes the range guard of the input map rides on the BatchNorm scale -- twelve
+    // multiplies by 1.0 in the common case instead of a select per value)
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(bt + 16 * m);
+        f32x4 sc = *reinterpret_cast<const f32x4*>(bt + 16 * m);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(bt + 48 + 16 * m);
+        if (!EVEN) sc *= up;
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
@@ -254,27 +283,33 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
                 if (EVEN) {
                     v = fmaf(v, inv, prev[j][m][r]);
                     prev[j][m][r] = v;
-                } else if (shift > 0) {
-                    v *= up;
                 }
                 acc[j][m][r] = fmaf(v, sc[r], sh[r]);
-                amax = fmaxf(amax, fabsf(acc[j][m][r]));
             }
     }
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {   // two values per v_max3_f32
+            amax = fmaxf(fmaxf(amax, fabsf(acc[j][m][0])), fabsf(acc[j][m][1]));
+            amax = fmaxf(fmaxf(amax, fabsf(acc[j][m][2])), fabsf(acc[j][m][3]));
+        }
     {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(bt + 16 * mx);
+        f32x4 sc = *reinterpret_cast<const f32x4*>(bt + 16 * mx);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(bt + 48 + 16 * mx);
+        if (!EVEN) sc *= up;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = relu1(accx[r]);
             if (EVEN) {
                 v = fmaf(v, inv, prevx[r]);
                 prevx[r] = v;
-            } else if (shift > 0) {
-                v *= up;
             }
             accx[r] = fmaf(v, sc[r], sh[r]);
-            if (c.xvalid) amax = fmaxf(amax, fabsf(accx[r]));
+        }
+        if (c.xvalid) {
+            amax = fmaxf(fmaxf(amax, fabsf(accx[0])), fabsf(accx[1]));
+            amax = fmaxf(fmaxf(amax, fabsf(accx[2])), fabsf(accx[3]));
         }
     }
     unsigned* const ggrp = reinterpret_cast<unsigned*>(c.red) + 4 * ((layer + 1) & 1);   // the reduction buffer is idle until the tail
@@ -283,7 +318,8 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
     __syncthreads();  // every wave has finished reading this layer's input map
     if (!LAST) {
         shift = __builtin_amdgcn_readfirstlane(range_shift(guard_read(ggrp)));   // uniform
-        if (shift > 0) {
+        if (shift > 0) {   // never taken for trained models: keep it a (wave-uniform) branch, not selects on every value
+            asm volatile("; range guard: scale the map down" ::: "memory");
             const float down = ldexpf(1.f, -shift);
 #pragma unroll
             for (int j = 0; j < 5; ++j)
@@ -344,7 +380,7 @@ size_t res8h_lds_bytes() { return (size_t)X_LDS_BYTES; }
 // physical CU -- HW_ID / XCC_ID arrival counters -- and delays of 30 / 60 / 90 k ticks: 13.62 - 13.76 ms, noise).
 // phase timestamps for tools/r8_phases.py: build with -DR8H_TIMING (they overwrite the consumed feature rows)
 #ifdef R8H_TIMING
-#define R8H_TS_DECL unsigned long long ts[8];
+#define R8H_TS_DECL unsigned long long ts[8], rt0 = __builtin_amdgcn_s_memrealtime();
 #define R8H_TS(i) ts[i] = __builtin_readcyclecounter();
 #else
 #define R8H_TS_DECL
@@ -368,10 +404,18 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 
     for (int i = threadIdx.x; i < BNT_WORDS; i += 256) bnt[i] = p.bn_tab[i];
 
-    for (int clip = blockIdx.x; clip < p.B; clip += gridDim.x) {
+    // Clips are handed out by a device-wide counter, not by a fixed stride: the two workgroups of a CU do NOT progress at
+    // the same rate (the SIMDs' arbiters favour the older waves: measured 84 against 106 us per clip, so with a static
+    // split the favoured workgroup of every CU sat idle for the last fifth of the launch), and the XCDs differ by a few
+    // per cent as well.  The first clip is blockIdx.x; p.queue starts at gridDim.x.  The counter is read one clip ahead
+    // (the atomic is in flight behind the feature loads) and published to the other waves through one LDS word.
+    int* const next_clip = reinterpret_cast<int*>(ldsb + NEXT_OFF);
+    for (int clip = blockIdx.x; clip < p.B;) {
         __syncthreads();  // previous clip's tail has consumed red/mvec and the map
         R8H_TS_DECL
         R8H_TS(0)
+        int taken = 0;
+        if (threadIdx.x == 0) taken = (int)atomicAdd(p.queue, 1u);
 
         // Everything derived from the lane id is recomputed per clip from an opaque copy of it.  Otherwise the compiler
         // hoists some 80 per-lane addresses and selectors out of this loop, keeps them alive across it and -- at 256
@@ -412,14 +456,16 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                     const int cell = idx + idx / 40 + FS + 1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {   // one word per feature: fp16 part 1 in the low half, part 2 in the high half
-                        const _Float16 hp = (_Float16)v[it][e];
-                        const f16x2 hl = {hp, (_Float16)(v[it][e] - (float)hp)};
-                        feat_w[cell + e] = __builtin_bit_cast(unsigned, hl);
+                        unsigned hl;
+                        asm("v_cvt_f16_f32 %0, %1" : "=v"(hl) : "v"(v[it][e]));
+                        asm("v_fma_mixhi_f16 %0, %0, -1.0, %1 op_sel_hi:[1,0,0]" : "+v"(hl) : "v"(v[it][e]));
+                        feat_w[cell + e] = hl;
                     }
                 }
             }
             if (tid < FS) feat_w[tid] = 0u;
             if (tid < 101) feat_w[(tid + 1) * FS] = 0u;
+            if (tid == 0) *next_clip = taken;
         }
         __syncthreads();
         R8H_TS(1)
@@ -560,6 +606,8 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         // every wave is done with the staged features: turn the region back into a map -- zero halo, then the pooled conv_0
         // output in its interior
         int shift;   // range guard of the map the next layer reads
+        AFrags fa_next;
+        if (R8H_PREFETCH) load_a(fa_next, reinterpret_cast<const u32x4*>(p.apk2) + c.lane, 0, mx);   // conv_1's first weight fragments
         {
             float amax = 0.f;
 #pragma unroll
@@ -580,34 +628,47 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
             *reinterpret_cast<u32x4*>(ldsb + (sub / 6) * PART_B + cell * CELL_B + (sub % 6) * 16) = (u32x4){0u, 0u, 0u, 0u};
         }
         shift = __builtin_amdgcn_readfirstlane(range_shift(guard_read(reinterpret_cast<const unsigned*>(c.red))));
-        {
-            const float down = shift > 0 ? ldexpf(1.f, -shift) : 1.f;
+        if (shift > 0) {   // (wave-uniform, never taken for trained models)
+            asm volatile("; range guard: scale the map down" ::: "memory");
+            const float down = ldexpf(1.f, -shift);
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
-                    store_split(c.lds, c.qb[j] + (16 * m + 4 * g) * 2, shift > 0 ? prev[j][m] * down : prev[j][m]);
-            if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, shift > 0 ? prevx * down : prevx);
+                for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + (16 * m + 4 * g) * 2, prev[j][m] * down);
+            if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, prevx * down);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + (16 * m + 4 * g) * 2, prev[j][m]);
+            if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, prevx);
         }
         __syncthreads();
 
         R8H_TS(3)
-        x_layer<TERMS, false, false>(p, c, 0, clip, prev, prevx, shift);
+        x_layer<TERMS, false, false>(p, c, 0, clip, prev, prevx, shift, fa_next);
         R8H_TS(4)
-        x_layer<TERMS, true, false>(p, c, 1, clip, prev, prevx, shift);
+        x_layer<TERMS, true, false>(p, c, 1, clip, prev, prevx, shift, fa_next);
         R8H_TS(5)
-        x_layer<TERMS, false, false>(p, c, 2, clip, prev, prevx, shift);
-        x_layer<TERMS, true, false>(p, c, 3, clip, prev, prevx, shift);
-        x_layer<TERMS, false, false>(p, c, 4, clip, prev, prevx, shift);
+        x_layer<TERMS, false, false>(p, c, 2, clip, prev, prevx, shift, fa_next);
+        x_layer<TERMS, true, false>(p, c, 3, clip, prev, prevx, shift, fa_next);
+        x_layer<TERMS, false, false>(p, c, 4, clip, prev, prevx, shift, fa_next);
         R8H_TS(6)
-        x_layer<TERMS, true, true>(p, c, 5, clip, prev, prevx, shift);
+        x_layer<TERMS, true, true>(p, c, 5, clip, prev, prevx, shift, fa_next);
         R8H_TS(7)
 #ifdef R8H_TIMING
         if ((threadIdx.x & 63) == 0) {      // the clip's features are dead: park the timestamps there (tools/r8_phases.py)
             unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.feat) + (size_t)clip * p.T * p.F) + 8 * w;
             for (int i = 0; i < 8; ++i) o[i] = ts[i];
+            if (w == 0) {   // 100 MHz wall clock over the same span: shader clock = d ticks / d realtime x 100 MHz
+                o[32] = rt0;
+                o[33] = __builtin_amdgcn_s_memrealtime();
+                o[34] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |   // XCC_ID
+                        (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                        // HW_ID
+            }
         }
 #endif
+        clip = *next_clip;   // written before the staging barrier of this clip; every wave reads it before the loop's top barrier
     }
 }
 
@@ -621,6 +682,8 @@ hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s) {
         if (e != hipSuccess) return e;
     }
     if (p.B <= 0) return hipSuccess;
+    hipError_t qe = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.queue), grid, 1, s);   // clips 0 .. grid-1 are taken by blockIdx
+    if (qe != hipSuccess) return qe;
     if (p.terms == 1)
         hipLaunchKernelGGL(res8h_kernel<1>, dim3((unsigned)grid), dim3(256), res8h_lds_bytes(), s, p);
     else

@@ -21,3 +21,21 @@ for clip in (5, 20000, 40000, 65000):
         ts = f[clip, 16 * w: 16 * w + 16].view(np.uint64).astype(np.int64)
         d = np.diff(ts)
         print(clip, w, ' '.join(f'{n}={int(v)}' for n, v in zip(names, d)), 'total', int(ts[-1] - ts[0]))
+    rt = f[clip, 64:68].view(np.uint64).astype(np.int64)
+    ts0 = f[clip, 0:16].view(np.uint64).astype(np.int64)
+    print(clip, 'realtime ticks (100 MHz)', int(rt[1] - rt[0]), '-> shader clock', round((ts0[-1] - ts0[0]) / max(int(rt[1] - rt[0]), 1) * 0.1, 3), 'GHz')
+
+# ---- whole-launch statistics from the 100 MHz wall clock stamps (wave 0 of every clip); a workgroup is identified by the
+#      hardware slot (XCC_ID, HW_ID) of its wave 0, which is constant over the launch
+rt = f[:, 64:68].copy().view(np.uint64).astype(np.int64)          # (B, 2): start, end of each clip in 10 ns ticks
+hw = f[:, 68:70].copy().view(np.uint64).astype(np.int64)[:, 0]
+np.savez_compressed('gpurun_out/r8_clip_times.npz', rt=rt, hw=hw)
+dur = (rt[:, 1] - rt[:, 0]) * 0.01                                 # us
+keys, wg = np.unique(hw, return_inverse=True)
+G = len(keys)
+span = np.array([(rt[wg == b, 1].max() - rt[wg == b, 0].min()) * 0.01 for b in range(G)])
+nclips = np.bincount(wg)
+t_all = (rt[:, 1].max() - rt[:, 0].min()) * 0.01
+print('workgroups seen', G, 'clips per workgroup: min %d mean %.1f max %d' % (nclips.min(), nclips.mean(), nclips.max()))
+print('per-clip us: mean %.1f  p5 %.1f  p50 %.1f  p95 %.1f  max %.1f' % (dur.mean(), *np.percentile(dur, [5, 50, 95]), dur.max()))
+print('per-workgroup span us: min %.0f  mean %.0f  max %.0f ; launch span %.0f us' % (span.min(), span.mean(), span.max(), t_all))
