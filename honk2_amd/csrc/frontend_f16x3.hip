@@ -16,8 +16,8 @@
 //     16-lane groups a ds_read_b128 is served in conflict-free.  The k order is free, so column j = 0 (weight 0) and
 //     columns 121..127 (weight 0) simply read whatever finite samples sit there.
 //   * |X|^2 goes to an LDS tile P[bin][frame] over the dead sample image (each cell has one Re and one Im owner); the
-//     mel stage runs with lane = frame (conflict-free rows) over packed non-zero taps, two bands per step; log and x2
-//     happen on the way out through a transposed tile so that the stores are whole rows.
+//     mel stage is a banded GEMM on the fp32-input MFMA whose accumulator layout is the output layout (a lane holds
+//     four consecutive bands of a frame): log and x2 happen in registers, rows leave as 16-byte stores.
 //   * Latency: the next unit's samples are requested (buffer loads, 76 registers the accumulators no longer need)
 //     before the mel stage and written to LDS after the output tile has been read; the unit's rows are stored last,
 //     because waiting for loads would otherwise wait for younger stores (one vmcnt).
@@ -44,8 +44,6 @@ constexpr int XS = 164;                                        // LDS words per 
 constexpr int NTT = FE16_NT;                                   // 16-frame tiles per unit
 constexpr int FRM = 16 * NTT;                                  // frames per unit
 constexpr int WG_PER_CU = NTT <= 4 ? 3 : 2;
-constexpr int SLOTS = FRM <= 64 ? 64 : 128;                    // mel stage: lanes per frame slot group
-constexpr int MEL_PARTS = 256 / SLOTS;                         // band ranges worked on in parallel
 constexpr int X_LEN = 160 * (FRM - 1) + FE_NFFT;               // staged samples: FRM + 2 hop blocks
 constexpr int X_WORDS = X_LEN + 4 * ((X_LEN + 159) / 160);
 constexpr int TILE_WORDS = 16 * XS;                            // LDS words between consecutive 16-frame tiles
@@ -53,11 +51,8 @@ constexpr int HW_WORDS = 256;                                  // h[j], h[240-j]
 constexpr float A_SCALE = 128.f;
 constexpr int PS = FRM + 6 - (FRM % 4);                        // row stride (words) of the power tile P[bin][frame]: = 2 mod 4
 static_assert(PS % 4 == 2 && PS >= FRM, "rows of lane groups 0 and 1 must start 16 banks apart");
-constexpr int P_ROWS = 120;                                    // bins the mel stage may read (FE16_MAX_BIN)
-constexpr int OUT_STRIDE = 41;                                 // transposed output tile [frame][band]
-constexpr int OUT_OFF = P_ROWS * PS;
-constexpr int IMG_WORDS0 = X_WORDS > OUT_OFF + FRM * OUT_STRIDE ? X_WORDS : OUT_OFF + FRM * OUT_STRIDE;
-constexpr int IMG_WORDS = IMG_WORDS0 > FE_ROWS * PS ? IMG_WORDS0 : FE_ROWS * PS;
+constexpr int IMG_WORDS = X_WORDS > FE_ROWS * PS ? X_WORDS : FE_ROWS * PS;   // the power tile replaces the (dead) sample image
+constexpr int MEL_SLOTS = (NTT + 3) / 4;                       // frame tiles per wave in the mel stage: tiles w, w + 4, ...
 constexpr int CONST_WORDS = FE16_CONST_WORDS;
 }  // namespace
 
@@ -76,16 +71,15 @@ __device__ __forceinline__ int fx_idx(int i) { return i + 4 * (i / 160); }
 template <int MODE>
 __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* hw = lds + IMG_WORDS;                                     // [window 256][mel taps][band table]: FE16_CONST_WORDS
-    float* taps = hw + HW_WORDS;
-    int* band = reinterpret_cast<int*>(taps + FE16_MAX_TAPS);
+    float* hw = lds + IMG_WORDS;                                     // [window 256]: FE16_CONST_WORDS
     unsigned* red = reinterpret_cast<unsigned*>(hw + CONST_WORDS);
+    int* const next_unit = reinterpret_cast<int*>(red + 4);          // the unit this workgroup takes next (see the loop)
     const int tid0 = threadIdx.x;
     const int n = p.n_samples;
     const int nunits = p.B * p.chunks;                               // a unit = (clip, 112-frame chunk)
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-    // ---- constants (window, packed mel taps, band table): once per workgroup
+    // ---- constants (the window halves): once per workgroup
 #pragma unroll
     for (int i = 0; i < (CONST_WORDS + 255) / 256; ++i)
         if (i * 256 + tid0 < CONST_WORDS) hw[i * 256 + tid0] = p.consts16[i * 256 + tid0];
@@ -216,13 +210,19 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
         if (lane == 63) red[w] = v;
     };
 
+    // Units are handed out by a device-wide counter (p.queue starts at gridDim.x; the first unit is blockIdx.x): the two
+    // workgroups of a CU do not progress at the same rate (res8_f16x3.hip), a fixed stride leaves the favoured one idle
+    // at the end.  The counter is read at the top of an iteration and published through one LDS word well before the
+    // prefetch of the next unit needs it.
     int unit = blockIdx.x;
     if (unit < nunits) {
         issue(unit, tid0);
         stage(unit, tid0);
     }
 #pragma unroll 1
-    for (; unit < nunits; unit += gridDim.x) {
+    while (unit < nunits) {
+    int taken = 0;
+    if (tid0 == 0) taken = (int)atomicAdd(p.queue, 1u);
     int tid = tid0;
     asm volatile("" : "+v"(tid));      // lane-derived values are recomputed per unit instead of living across the loop
     const int lane = tid & 63;
@@ -313,11 +313,21 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
         const float xc[8] = {NS, N1[3], N1[2], N1[1], N1[0], N0[3], N0[2], N0[1]};
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
+#ifdef FE16_PK_MATH     // packed fp32 math: half the fold / window instructions, but each pair has to sit in adjacent registers
             const f32x2 u = {fmaf(sgn, xb[e], xa[e]), fmaf(sgn, xb[e + 1], xa[e + 1])};
             const f32x2 v = {fmaf(sgn, xd[e], xc[e]), fmaf(sgn, xd[e + 1], xc[e + 1])};
             const f32x2 q = (f32x2){k.hc[e], k.hc[e + 1]} * v;
             const f32x2 b = __builtin_elementwise_fma((f32x2){k.hj[e], k.hj[e + 1]}, u, q);
-            const f16x2 h = {(_Float16)b[0], (_Float16)b[1]};
+#else                   // plain FMAs: no register pairing (the mirrored streams arrive in descending order), no packed-op issue cost
+            float b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float u = fmaf(sgn, xb[e + i], xa[e + i]);
+                const float v = fmaf(sgn, xd[e + i], xc[e + i]);
+                b[i] = fmaf(k.hj[e + i], u, k.hc[e + i] * v);
+            }
+#endif
+            const f16x2 h = __builtin_convertvector((f32x2){b[0], b[1]}, f16x2);   // one v_cvt_pk_f16_f32 (round to nearest even)
             const unsigned hp = __builtin_bit_cast(unsigned, h);
             // l = fp16(b - h): the mixed-precision FMA reads h from its half of the packed register and writes the
             // rounded fp16 result into the low / high half of the destination
@@ -384,6 +394,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
                 sq[m][j][hh] = x * x;
             }
     }
+    if (tid == 0) *next_unit = taken;
     __syncthreads();  // every wave is done with the sample image
 
     // ---- power tile P[bin][frame] = Re^2 + Im^2 (row stride PS words).  Each cell has one Re and one Im owner: in
@@ -405,90 +416,105 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     if (w < 2) { P_PHASE(2, *cell += v) } else { P_PHASE(0, *cell += v) }
 #undef P_PHASE
     __syncthreads();
-    issue(min(unit + (int)gridDim.x, nunits - 1), tid);   // the accumulators are dead: prefetch the next unit's samples
+    const int nxt = *next_unit;
+    issue(min(nxt, nunits - 1), tid);   // the accumulators are dead: prefetch the next unit's samples
 
     FE16_TS(4)
-    // ---- mel + log + "DCT of length 1" (x2).  Lane = frame (consecutive lanes read consecutive words of a bin's row:
-    //      no bank conflicts), waves 0-1 take the bands below mel_split, waves 2-3 the rest; weights are LDS broadcasts
-    //      of the packed non-zero taps.  Results go through a transposed LDS tile so that the stores are whole rows.
+    // ---- mel + log + "DCT of length 1" (x2).  mel = W (bands x bins) . P (bins x frames) is a banded GEMM: band tile m (16
+    //      bands) only meets the bins of its own filters, p.mel_ns[m] k-steps of four bins (33 steps for the 40-band bank
+    //      instead of 3 x 32).  It runs on the fp32-input MFMA (exact fp32 products and sums; the pipe is otherwise idle
+    //      here): wave w takes frame tiles w and w + 4, one A fragment (global, 8 KB table, L1-resident) and one ds_read_b32
+    //      per tile and step.  The result leaves in accumulator layout -- a lane holds four consecutive bands of one
+    //      frame, 16 bytes of the output row -- so there is no transposed tile, no second pass over LDS and one barrier
+    //      less than with the band-per-lane FMA chains this replaces (8-10 k + 4.5 k cycles per unit -> ~4 k).
+    f32x4 macc[MEL_SLOTS][3];
+#pragma unroll
+    for (int q = 0; q < MEL_SLOTS; ++q)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) macc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-        const int tl = tid & (SLOTS - 1);
-        const int part = __builtin_amdgcn_readfirstlane(tid / SLOTS);
-        const int f_lo = p.mel_bounds[part], f_hi = p.mel_bounds[part + 1];
-        float* outt = lds + OUT_OFF;
-        if (tl < nfr) {
-            const float* pr = lds + tl;
-            // two bands per step (two independent FMA chains); the host pads both to the same number of groups of
-            // four taps; a padded tap has weight 0 and re-reads an existing row
-            for (int f = f_lo; f < f_hi; f += 2) {
-                const int f1 = min(f + 1, f_hi - 1);
-                const int lo0 = __builtin_amdgcn_readfirstlane(band[2 * f]);
-                const int off0 = __builtin_amdgcn_readfirstlane(band[2 * f + 1]);
-                const int ng = (__builtin_amdgcn_readfirstlane(band[2 * f + 3]) - off0) >> 2;
-                const int lo1 = __builtin_amdgcn_readfirstlane(band[2 * f1]);
-                const int off1 = __builtin_amdgcn_readfirstlane(band[2 * f1 + 1]);
-                const f32x4* wt0 = reinterpret_cast<const f32x4*>(taps + off0);
-                const f32x4* wt1 = reinterpret_cast<const f32x4*>(taps + off1);
-                float v0 = 0.f, v1 = 0.f;
-#define MEL_BODY(NG)                                                                                  \
-    {                                                                                                 \
-        f32x4 wq0[NG], wq1[NG];                                                                       \
-        float x0[4 * NG], x1[4 * NG];                                                                 \
-        _Pragma("unroll") for (int q = 0; q < NG; ++q) {                                              \
-            wq0[q] = wt0[q];                                                                          \
-            wq1[q] = wt1[q];                                                                          \
-        }                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4 * NG; ++i) {                                          \
-            x0[i] = pr[min(lo0 + i, P_ROWS - 1) * PS];                                                \
-            x1[i] = pr[min(lo1 + i, P_ROWS - 1) * PS];                                                \
-        }                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4 * NG; ++i) {                                          \
-            v0 = fmaf(wq0[i >> 2][i & 3], x0[i], v0);                                                 \
-            v1 = fmaf(wq1[i >> 2][i & 3], x1[i], v1);                                                 \
-        }                                                                                             \
-    }
-                if (ng <= 1) MEL_BODY(1) else if (ng == 2) MEL_BODY(2) else if (ng == 3) MEL_BODY(3) else MEL_BODY(4)
-#undef MEL_BODY
-                outt[tl * OUT_STRIDE + f] = v0;
-                outt[tl * OUT_STRIDE + f1] = v1;
+        const float* atab = p.mel_a + lane;
+        int pcol_off[MEL_SLOTS];
+#pragma unroll
+        for (int q = 0; q < MEL_SLOTS; ++q) pcol_off[q] = 16 * min(w + 4 * q, NTT - 1) + pcol;   // a tile past the end re-reads the last one
+        int step = 0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int ns = p.mel_ns[m];
+            const float* prow = lds + (4 * p.mel_fb[m] + g) * PS;
+            for (int s0 = 0; s0 < ns; s0 += 4, step += 4) {   // the host pads every tile to a multiple of four steps
+                float a[4], x[4][MEL_SLOTS];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = atab[(step + u) * 64];
+#pragma unroll
+                    for (int q = 0; q < MEL_SLOTS; ++q) x[u][q] = prow[4 * (s0 + u) * PS + pcol_off[q]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < MEL_SLOTS; ++q)
+                        macc[q][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], x[u][q], macc[q][m], 0, 0, 0);
             }
         }
     }
     FE16_TS(5)
-    __syncthreads();
-    FE16_TS(6)
-    // ---- log and x2 ("DCT of length 1") on the way out.  The values are read and finished into registers first; then
-    //      (after a barrier) the next unit's samples go into the image region, and only then are the rows stored:
-    //      waiting for the prefetched samples must not wait for this unit's stores (one counter covers both).
-    constexpr int COPY_IT = (FRM * FE16_MAX_MELS + 255) / 256;
-    float outv[COPY_IT];
-    const int nout = nfr * p.n_mels;
-    {
-        const float* outt = lds + OUT_OFF;
-        const int dq = 256 / p.n_mels, dr = 256 - dq * p.n_mels;
-        int tl = tid / p.n_mels, f = tid - tl * p.n_mels;
+    // log and x2 in registers: D[band 16 m + 4 g + r][frame 16 (w + 4 q) + pcol].  v_log_f32 flushes subnormal inputs; powers
+    // that small (below 1e-30: digital near-silence) are rare, so ONE test covers all of a lane's values and the exact
+    // logf() runs for the lanes that need it, instead of a branch per value
+    f32x4 outv[MEL_SLOTS][3];
+    bool tiny = false;
 #pragma unroll
-        for (int it = 0; it < COPY_IT; ++it) {      // straight-line: elements past the end re-read the tile's last word
-            const float v = outt[min(tl * OUT_STRIDE + f, FRM * OUT_STRIDE - 1)];
-            float lg = v >= 1e-30f ? __logf(v) : v;
-            if (__builtin_expect(v > 0.f && v < 1e-30f, 0)) lg = logf(v);      // subnormal-range powers: the slow exact path
-            outv[it] = 2.0f * lg;
-            f += dr;
-            tl += dq;
-            if (f >= p.n_mels) {
-                f -= p.n_mels;
-                ++tl;
+    for (int q = 0; q < MEL_SLOTS; ++q)
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = macc[q][m][r];
+                tiny |= v > 0.f && v < 1e-30f;
+                outv[q][m][r] = v >= 1e-30f ? 1.3862943611198906f * __builtin_amdgcn_logf(v) : 2.0f * v;   // 2 ln 2 log2 v (bare v_log_f32)
             }
-        }
+    if (__builtin_expect(tiny, 0)) {
+#pragma unroll 1
+        for (int i = 0; i < MEL_SLOTS * 3; ++i)
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) {
+                const int q = i / 3, m = i - 3 * q;
+                float v = 0.f;
+#pragma unroll
+                for (int qq = 0; qq < MEL_SLOTS; ++qq)          // (register arrays: select with compile-time indices)
+#pragma unroll
+                    for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+                            if (qq == q && mm == m && rr == r) v = macc[qq][mm][rr];
+                if (v > 0.f && v < 1e-30f) {
+                    const float fix = 2.0f * logf(v);
+#pragma unroll
+                    for (int qq = 0; qq < MEL_SLOTS; ++qq)
+#pragma unroll
+                        for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr)
+                                if (qq == q && mm == m && rr == r) outv[qq][mm][rr] = fix;
+                }
+            }
     }
+    FE16_TS(6)
     FE16_TS(7)
-    __syncthreads();   // the output tile and the power tile are dead: the next unit's samples may overwrite them
-    if (unit + (int)gridDim.x < nunits) stage(unit + gridDim.x, tid);
-    {
+    __syncthreads();   // every wave has read the power tile: the next unit's samples may overwrite it
+    if (nxt < nunits) stage(nxt, tid);
+    {   // the unit's rows are stored last: waiting for the prefetched samples must not wait for these stores (one vmcnt)
         float* dst = p.feat + ((size_t)clip * p.T + t0) * p.n_mels;
 #pragma unroll
-        for (int it = 0; it < COPY_IT; ++it)
-            if (it * 256 + tid < nout) dst[it * 256 + tid] = outv[it];
+        for (int q = 0; q < MEL_SLOTS; ++q) {
+            const int jt = w + 4 * q, frame = 16 * jt + pcol;
+            if (jt < NTT && frame < nfr) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                    if (16 * m + 4 * g < p.n_mels) *reinterpret_cast<f32x4*>(dst + (size_t)frame * p.n_mels + 16 * m + 4 * g) = outv[q][m];
+            }
+        }
     }
 #ifdef FE16_TIMING
     if (lane == 0) {
@@ -498,15 +524,46 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
         o[8] = t8;
     }
 #endif
+    unit = nxt;
     }
 }
 
 int frontend_f16_frames() { return FRM; }
-int frontend_f16_mel_parts() { return MEL_PARTS; }
+
+// Banded mel GEMM (see the kernel's mel stage): k-steps of four bins per 16-band tile; n_mels must be a multiple of four
+// (a lane stores four consecutive bands with one 16-byte store) and at most 48.
+bool build_mel_gemm_table(const std::vector<float>& wts, const std::vector<int>& lo, const std::vector<int>& hi, int n_mels,
+                          std::vector<float>& tab, int (&fb)[3], int (&ns)[3]) {
+    if (n_mels <= 0 || n_mels > FE16_MAX_MELS || n_mels % 4) return false;
+    int total = 0;
+    for (int m = 0; m < 3; ++m) {
+        int b_lo = FE_ROWS, b_hi = 0;
+        for (int f = 16 * m; f < std::min(n_mels, 16 * m + 16); ++f)
+            if (hi[f] > lo[f]) {
+                b_lo = std::min(b_lo, lo[f]);
+                b_hi = std::max(b_hi, hi[f]);
+            }
+        fb[m] = b_hi > b_lo ? b_lo / 4 : 0;
+        ns[m] = b_hi > b_lo ? ((b_hi + 3) / 4 - fb[m] + 3) / 4 * 4 : 0;     // padded to a multiple of four steps (zero weights)
+        if (4 * (fb[m] + ns[m]) > FE_ROWS) fb[m] = FE_ROWS / 4 - ns[m];      // the padding goes in front instead
+        if (fb[m] < 0) return false;
+        total += ns[m];
+    }
+    if (total > FE16_MAX_STEPS) return false;
+    tab.assign((size_t)std::max(total, 1) * 64, 0.f);
+    int step = 0;
+    for (int m = 0; m < 3; ++m)
+        for (int s = 0; s < ns[m]; ++s, ++step)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int f = 16 * m + (lane & 15), k = 4 * (fb[m] + s) + (lane >> 4);
+                if (f < n_mels && k < FE_ROWS) tab[(size_t)step * 64 + lane] = wts[(size_t)f * FE_ROWS + k];
+            }
+    return true;
+}
 
 size_t frontend_f16_lds_bytes() {
     static_assert(FE_ROWS * PS <= IMG_WORDS, "power tile must fit the image region");
-    const size_t words = (size_t)IMG_WORDS + CONST_WORDS + 4;
+    const size_t words = (size_t)IMG_WORDS + CONST_WORDS + 8;
     return ((words * sizeof(float)) + 15) & ~(size_t)15;
 }
 
@@ -524,6 +581,8 @@ hipError_t launch_frontend_f16(const FrontendParams& p, int n_cu, hipStream_t s)
     static const int wgs_env = std::getenv("KWS_FE_WGS_PER_CU") ? std::atoi(std::getenv("KWS_FE_WGS_PER_CU")) : 0;   // experiments
     const int wgs = wgs_env > 0 && wgs_env < WG_PER_CU ? wgs_env : WG_PER_CU;
     const dim3 grid((unsigned)std::min<long long>(units, (long long)wgs * n_cu));      // persistent
+    hipError_t qe = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.queue), (int)grid.x, 1, s);   // units 0 .. grid-1 go by blockIdx
+    if (qe != hipSuccess) return qe;
     if (p.wav) hipLaunchKernelGGL(frontend_f16_kernel<0>, grid, dim3(256), lds, s, p);
     else if (!p.noise) hipLaunchKernelGGL(frontend_f16_kernel<1>, grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL(frontend_f16_kernel<2>, grid, dim3(256), lds, s, p);

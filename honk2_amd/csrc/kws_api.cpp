@@ -82,10 +82,10 @@ struct kws_handle {
     LwMode lw_mode = LW_TILED;
 
     // front end
-    DevMem dft, hann, dft16, consts16, melw, mel_lo, mel_hi, edge_hann, edge_trig;
+    DevMem dft, hann, dft16, consts16, melw, mel_lo, mel_hi, edge_hann, edge_trig, mel_a;
     bool fe_fp32 = false;                  // KWS_FRONTEND_IMPL=fp32: the fp32-input MFMA front end (frontend.hip)
-    int mel_maxw = 0, mel_ntaps = 0, mel_maxbin = 0;
-    int mel_bounds[5] = {0, 0, 0, 0, 0};
+    int mel_maxw = 0;
+    int mel_fb[3] = {0, 0, 0}, mel_ns[3] = {0, 0, 0};   // banded mel GEMM of the fp16 front end (kws_internal.h)
 
     // parameters
     std::set<std::string> required, loaded;
@@ -198,43 +198,15 @@ int setup_frontend(kws_handle* h) {
     std::vector<float> hann2;
     build_dft_table_f16(tab16, hann2);
     if ((rc = h->dft16.upload(tab16.data(), tab16.size() * sizeof(unsigned)))) return rc;
-    // constants of the fp16 front end, one blob: window; non-zero mel taps band after band; (first bin, tap offset)
-    // per band.  Its mel stage works on 2 or 4 band ranges in parallel, two bands per step: the ranges split the
-    // estimated cost (a fixed part per step + its groups of four taps) evenly, the two bands of a step are padded to the
-    // same number of groups.
-    std::vector<int> ng(d.n_mels);
-    int cost_all = 0;
-    for (int i = 0; i < d.n_mels; ++i) {
-        ng[i] = std::max(1, (hi[i] - lo[i] + 3) / 4);
-        cost_all += 4 + ng[i];
-        h->mel_maxbin = std::max(h->mel_maxbin, hi[i]);
-    }
-    const int parts = frontend_f16_mel_parts();
-    h->mel_bounds[0] = 0;
-    for (int q = 1, i = 0, c = 0; q <= parts; ++q) {      // bounds[q] = first band at which q / parts of the cost is done
-        while (i < d.n_mels && parts * c < q * cost_all) c += 4 + ng[i++];
-        h->mel_bounds[q] = q == parts ? d.n_mels : i;
-    }
-    for (int q = parts + 1; q <= 4; ++q) h->mel_bounds[q] = d.n_mels;
-    for (int q = 0; q < parts; ++q)
-        for (int f = h->mel_bounds[q]; f + 1 < h->mel_bounds[q + 1]; f += 2) ng[f] = ng[f + 1] = std::max(ng[f], ng[f + 1]);
+    // constants of the fp16 front end: the window halves (LDS blob) and the banded mel GEMM's A fragments
     std::vector<float> blob(FE16_CONST_WORDS, 0.f);
     std::copy(hann2.begin(), hann2.end(), blob.begin());
-    int* bandtab = reinterpret_cast<int*>(blob.data() + 256 + FE16_MAX_TAPS);
-    int ntaps = 0;
-    for (int i = 0; i < d.n_mels && d.n_mels <= FE16_MAX_MELS; ++i) {
-        bandtab[2 * i] = lo[i];
-        bandtab[2 * i + 1] = ntaps;
-        for (int k = lo[i]; k < hi[i] && ntaps + (k - lo[i]) < FE16_MAX_TAPS; ++k)
-            blob[256 + ntaps + (k - lo[i])] = wts[(size_t)i * FE_ROWS + k];
-        ntaps += 4 * ng[i];
-        bandtab[2 * i + 3] = ntaps;       // the next band's offset (end marker after the last band)
-    }
-    h->mel_ntaps = ntaps;
     if ((rc = h->consts16.upload(blob.data(), blob.size() * sizeof(float)))) return rc;
+    std::vector<float> mel_tab;
+    const bool mel_fits = build_mel_gemm_table(wts, lo, hi, d.n_mels, mel_tab, h->mel_fb, h->mel_ns);
+    if (mel_fits && (rc = h->mel_a.upload(mel_tab.data(), mel_tab.size() * sizeof(float)))) return rc;
     const char* fimpl = std::getenv("KWS_FRONTEND_IMPL");
-    h->fe_fp32 = (fimpl && std::strcmp(fimpl, "fp32") == 0) || h->mel_ntaps > FE16_MAX_TAPS || d.n_mels > FE16_MAX_MELS || h->mel_maxw > 16 ||
-                 h->mel_maxbin > FE16_MAX_BIN;   // filterbanks the fp16 kernel's LDS tables cannot hold
+    h->fe_fp32 = (fimpl && std::strcmp(fimpl, "fp32") == 0) || !mel_fits;   // filterbanks the fp16 kernel's mel stage cannot hold
     std::vector<float> ehann, etrig;
     build_edge_tables(ehann, etrig);
     if ((rc = h->edge_hann.upload(ehann.data(), ehann.size() * sizeof(float)))) return rc;
@@ -1021,8 +993,9 @@ static int mfcc_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, con
     FrontendParams p{d_wav, reinterpret_cast<const short*>(d_pcm), d_noise, noise_pct, d_feat, h->dft.as<f32x4>(),
                      h->hann.as<float>(), h->melw.as<float>(), h->mel_lo.as<int>(), h->mel_hi.as<int>(), B, n_samples, T,
                      h->d.n_mels, (T + FE_FRAMES - 1) / FE_FRAMES, h->mel_maxw, clip_stride < 0 ? n_samples : clip_stride,
-                     h->dft16.as<void>(), h->consts16.as<float>(), {h->mel_bounds[0], h->mel_bounds[1], h->mel_bounds[2],
-                                                                    h->mel_bounds[3], h->mel_bounds[4]}};
+                     h->dft16.as<void>(), h->consts16.as<float>(), h->mel_a.as<float>(),
+                     {h->mel_fb[0], h->mel_fb[1], h->mel_fb[2]}, {h->mel_ns[0], h->mel_ns[1], h->mel_ns[2]},
+                     h->range_flag.as<unsigned>() + 32};
     // the fp16 kernel reads whole 16-byte groups: rows (and base pointers) that are not 16-byte aligned -- odd clip
     // lengths, sliced buffers -- take the fp32-input kernel, which stages element-wise
     const bool aligned = (p.clip_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(d_wav) | reinterpret_cast<uintptr_t>(d_noise)) & 15) == 0 &&

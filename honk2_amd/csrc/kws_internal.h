@@ -121,11 +121,19 @@ struct FrontendParams {
     int mel_maxw;         // widest mel filter in bins (fast path keeps <= 16 weights in registers)
     long long clip_stride;   // samples between the starts of consecutive clips (n_samples for a packed batch)
     const void* dft16;    // fp16 two-part cos/sin fragments (frontend_f16x3.hip)
-    const float* consts16;   // FE16_CONST_WORDS: h[j] (128), h[240-j] (128); mel taps; (first bin, tap offset) per band
-    int mel_bounds[5];       // band ranges of the (2 or 4) parts of the mel work: part i = [bounds[i], bounds[i + 1])
+    const float* consts16;   // FE16_CONST_WORDS: h[j] (128), h[240-j] (128)
+    // mel stage of frontend_f16_kernel = a banded GEMM on the fp32-input matrix cores: band tile m (16 bands) covers the
+    // k-steps mel_fb[m] .. mel_fb[m] + mel_ns[m] - 1 of four DFT bins each; mel_a holds their A fragments, step after step
+    // over m = 0, 1, 2: [step][lane] = W[16 m + (lane & 15)][4 (fb + s) + (lane >> 4)]
+    const float* mel_a;
+    int mel_fb[3], mel_ns[3];
+    unsigned* queue;         // device word: next unit to hand out (frontend_f16_kernel; its launcher sets it to the grid size)
 };
-constexpr int FE16_MAX_TAPS = 768, FE16_MAX_MELS = 40, FE16_MAX_BIN = 120;   // what frontend_f16_kernel's LDS tables hold
-constexpr int FE16_CONST_WORDS = 256 + FE16_MAX_TAPS + 2 * FE16_MAX_MELS + 4;
+constexpr int FE16_MAX_MELS = 48, FE16_MAX_STEPS = 64;   // what frontend_f16_kernel's mel stage holds: three band tiles, 64 k-steps
+constexpr int FE16_CONST_WORDS = 256;
+// host side: the banded-GEMM table of a filterbank (n_mels, FE_ROWS) with per-band bin ranges [lo, hi); false if it does not fit
+bool build_mel_gemm_table(const std::vector<float>& wts, const std::vector<int>& lo, const std::vector<int>& hi, int n_mels,
+                          std::vector<float>& tab, int (&fb)[3], int (&ns)[3]);
 // streaming windows whose shift is a multiple of the hop: edge frames + copy of the shared rows (frontend.hip)
 struct WindowEdgeParams {
     const float* stream;        // the long waveform; window i starts at sample i * shift
@@ -145,7 +153,6 @@ hipError_t launch_frontend(const FrontendParams& p, hipStream_t s);
 void build_dft_table(std::vector<float>& dft, std::vector<float>& hann);  // host side, double precision trig
 hipError_t launch_frontend_f16(const FrontendParams& p, int n_cu, hipStream_t s);
 int frontend_f16_frames();      // frames per unit (chunk) of frontend_f16_kernel
-int frontend_f16_mel_parts();   // 2 or 4     // frontend_f16x3.hip (default)
 void build_dft_table_f16(std::vector<unsigned>& tab, std::vector<float>& hann2);
 
 // ---------------------------------------------------------------- fused res8 (res8_fused.hip)

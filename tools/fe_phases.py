@@ -7,7 +7,7 @@ ap = AudioProcessor()
 wav = (0.1 * torch.randn(65536, 16000, device='cuda')).clamp(-1, 1)
 ap.compute_mfccs_batch(wav)
 f = ap.compute_mfccs_batch(wav).cpu().numpy()
-names = ['top', 'barrier', 'kloop', 'power+issue', 'mel', 'barrier2', 'copyout', 'stage_next']
+names = ['top', 'barrier', 'kloop', 'power+issue', 'mel', 'log', '-', 'stage_next+store']
 for clip in (5, 20000, 40000, 65000):
     for w in range(4):
         row = f[clip, 1 + w * 8: 1 + w * 8 + 1 + 1].reshape(-1)[:16 * 1]

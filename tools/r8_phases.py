@@ -29,7 +29,8 @@ for clip in (5, 20000, 40000, 65000):
 #      hardware slot (XCC_ID, HW_ID) of its wave 0, which is constant over the launch
 rt = f[:, 64:68].copy().view(np.uint64).astype(np.int64)          # (B, 2): start, end of each clip in 10 ns ticks
 hw = f[:, 68:70].copy().view(np.uint64).astype(np.int64)[:, 0]
-np.savez_compressed('gpurun_out/r8_clip_times.npz', rt=rt, hw=hw)
+ts_all = f[:, 0:64].copy().view(np.uint64).astype(np.int64).reshape(B, 4, 8)
+np.savez_compressed('gpurun_out/r8_clip_times.npz', rt=rt, hw=hw, ts=ts_all)
 dur = (rt[:, 1] - rt[:, 0]) * 0.01                                 # us
 keys, wg = np.unique(hw, return_inverse=True)
 G = len(keys)
