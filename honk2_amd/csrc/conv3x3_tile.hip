@@ -85,14 +85,19 @@ __device__ __forceinline__ int layout_cell(int b, int y, int x, int ld, int H, i
     return (((b << (2 * ld)) + sub) * Hs + (y >> ld)) * Ws + (x >> ld);
 }
 
-// two fp16 parts (x = h + l to 22 bits) of four fp32 values
+// two fp16 parts (x = h + l to 22 bits) of four fp32 values: one packed convert + one mixed-precision FMA per value
+// (l = fp16(x - float(h)); the difference is exact in fp32, so this equals convert-back / subtract / convert bit for bit:
+// tools/split_probe.cpp).  The results go to LDS stores, not straight into an MFMA (no hazard padding needed).
 __device__ __forceinline__ void split4_f16(f32x4 x, u32x2 (&out)[2]) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const f16x2 h = {(_Float16)x[2 * i], (_Float16)x[2 * i + 1]};
-        const f16x2 l = {(_Float16)(x[2 * i] - (float)h[0]), (_Float16)(x[2 * i + 1] - (float)h[1])};
-        out[0][i] = __builtin_bit_cast(unsigned, h);
-        out[1][i] = __builtin_bit_cast(unsigned, l);
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){x[2 * i], x[2 * i + 1]}, f16x2));
+        unsigned l;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x[2 * i]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x[2 * i + 1]));
+        out[0][i] = h;
+        out[1][i] = l;
     }
 }
 

@@ -333,7 +333,9 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
             // rounded fp16 result into the low / high half of the destination
             unsigned lp;
             asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(b[0]));
-            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(b[1]));
+            // (s_nop 1: two wait states between a VALU result and a matrix instruction reading it -- hipcc pads nothing for
+            // instructions inside an asm statement; the fragment is built one step ahead, this is the belt to those braces)
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(lp) : "v"(hp), "v"(b[1]));
             bh[e >> 1] = hp;
             bl[e >> 1] = lp;
         }

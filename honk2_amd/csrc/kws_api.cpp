@@ -114,7 +114,8 @@ struct kws_handle {
     // workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    DevMem range_flag;                     // one device word: fp16 range guard of the layer-wise plans (kws_internal.h)
+    DevMem range_flag;                     // device words: [0] fp16 range guard of the layer-wise plans (kws_internal.h), [16] /
+                                           // [32] clip / unit counters of the fused res8 and front-end kernels
 
     // profiling
     bool prof = false;

@@ -59,13 +59,21 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&out)[3]) {
 }
 
 // 8 fp32 values -> two fp16x8 fragments (x = h + l to 22 bits; exact products in three terms, see res8_f16x3.hip)
+// (one packed convert + one mixed-precision FMA per value: l = fp16(x - float(h)), exact difference, same bits as
+// convert-back / subtract / convert at a third of the instructions -- this kernel is bound by exactly this VALU work)
 __device__ __forceinline__ void split8_f16(const float (&x)[8], u32x4 (&out)[3]) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const f16x2 h = {(_Float16)x[2 * i], (_Float16)x[2 * i + 1]};
-        const f16x2 l = {(_Float16)(x[2 * i] - (float)h[0]), (_Float16)(x[2 * i + 1] - (float)h[1])};
-        out[0][i] = __builtin_bit_cast(unsigned, h);
-        out[1][i] = __builtin_bit_cast(unsigned, l);
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){x[2 * i], x[2 * i + 1]}, f16x2));
+        unsigned l;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x[2 * i]));
+        // the fragment goes straight into an MFMA: hipcc pads no hazards for instructions inside an asm statement, and a VALU
+        // result needs two wait states before a matrix instruction may read it (without them the last pair's second part
+        // was stale in the multi-pass pooling variants, where nothing else sits in between: logits off by 1e-2)
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "+v"(l) : "v"(h), "v"(x[2 * i + 1]));
+        out[0][i] = h;
+        out[1][i] = l;
     }
 }
 

@@ -34,21 +34,53 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-// part-major map: [2 parts][384 cells][48 channels] fp16.  A cell is 96 B = 6 slots of 16 B, so eight consecutive cells
-// start in eight different even (or odd) slots of the 16 a bank row has, and the two k-groups a ds_read_b128 lane
-// group mixes read channel blocks of opposite parity: B-fragment reads conflict only where a position tile wraps to
-// the next map row (cell-major [cell][part][channel], 192-B cells: 2.8x the conflict-free LDS cycles on reads, 8x on
-// the epilogue's 8-byte stores; this layout 2.0x / 4.6x, model in DESIGN.md section 4.2)
-constexpr int CELL_B = 96;                            // bytes per map cell and part: 48 channels x 2
-constexpr int PART_B = 384 * CELL_B;                  // 36 864
+// Channel-block-major map: [2 parts][6 blocks of 8 channels][384 cells] x 16 B; cell(y, x) = 14 (y + 1) + x + 1 (one shared
+// zero halo column between rows).  A ds_read_b128 of a B fragment is served in four 16-lane groups, each of which holds
+// all 16 positions of the tile (8 lanes of one k-group + the complementary 8 of the next k-group, whose plane starts a
+// multiple of 256 B further on), so it is conflict-free iff the tile's 16 cells are distinct mod 16.  Consecutive
+// positions never are (a 13-wide row wraps inside every tile: the cell-per-position layouts before this one cost
+// 2.0x - 2.8x the conflict-free LDS cycles on reads, 4.6x - 8x on the epilogue's 8-byte stores, and
+// SQ_LDS_BANK_CONFLICT was 54 % of the LDS pipe's active cycles), but the MFMA does not care which positions share a
+// tile: tiles 0..19 take ONE position from each residue class of cell index mod 16 (18..22 cells per class; a class that
+// has run out leaves a pad lane, which clones another lane of its tile: same address = broadcast) and tile 20 takes
+// the 15 positions left over.  Modelled LDS cycles per layer: reads 2 572 (ideal 2 352; 4 664 before), stores 1 056
+// (504; 2 328).  The table comes from tools/r8_tiles.py, which also holds the bank model.
+constexpr int PLANE_B = 384 * 16;                     // one (part, channel block) plane: 6 144 B
+constexpr int PART_B = 6 * PLANE_B;                   // 36 864
 constexpr int MAP_BYTES = 2 * PART_B;                 // 73 728
+// position (0..324, row-major over the 25 x 13 map) of lane pcol of tile t at [16 t + pcol]; 0x8000 marks a pad lane
+__device__ const unsigned short R8H_POS[21 * 16] = {
+    0x0001, 0x0002, 0x0003, 0x0004, 0x0005, 0x0006, 0x0007, 0x0008, 0x0009, 0x000a, 0x000b, 0x000c, 0x001b, 0x000d, 0x000e, 0x0000,
+    0x0010, 0x0011, 0x0012, 0x0013, 0x0014, 0x0015, 0x0016, 0x0017, 0x0018, 0x0019, 0x0028, 0x001a, 0x002a, 0x001c, 0x001d, 0x000f,
+    0x001f, 0x0020, 0x0021, 0x0022, 0x0023, 0x0024, 0x0025, 0x0026, 0x0035, 0x0027, 0x0037, 0x0029, 0x0039, 0x002b, 0x002c, 0x001e,
+    0x002e, 0x002f, 0x0030, 0x0031, 0x0032, 0x0033, 0x0042, 0x0034, 0x0044, 0x0036, 0x0046, 0x0038, 0x0048, 0x003a, 0x003b, 0x002d,
+    0x003d, 0x003e, 0x003f, 0x0040, 0x004f, 0x0041, 0x0051, 0x0043, 0x0053, 0x0045, 0x0055, 0x0047, 0x0057, 0x0049, 0x004a, 0x003c,
+    0x004c, 0x004d, 0x005c, 0x004e, 0x005e, 0x0050, 0x0060, 0x0052, 0x0062, 0x0054, 0x0064, 0x0056, 0x0066, 0x0058, 0x0059, 0x004b,
+    0x0069, 0x005b, 0x006b, 0x005d, 0x006d, 0x005f, 0x006f, 0x0061, 0x0071, 0x0063, 0x0073, 0x0065, 0x0083, 0x0067, 0x0076, 0x005a,
+    0x0078, 0x006a, 0x007a, 0x006c, 0x007c, 0x006e, 0x007e, 0x0070, 0x0080, 0x0072, 0x0090, 0x0074, 0x0092, 0x0075, 0x0085, 0x0068,
+    0x0087, 0x0079, 0x0089, 0x007b, 0x008b, 0x007d, 0x008d, 0x007f, 0x009d, 0x0081, 0x009f, 0x0082, 0x00a1, 0x0084, 0x0094, 0x0077,
+    0x0096, 0x0088, 0x0098, 0x008a, 0x009a, 0x008c, 0x00aa, 0x008e, 0x00ac, 0x008f, 0x00ae, 0x0091, 0x00b0, 0x0093, 0x00a3, 0x0086,
+    0x00a5, 0x0097, 0x00a7, 0x0099, 0x00b7, 0x009b, 0x00b9, 0x009c, 0x00bb, 0x009e, 0x00bd, 0x00a0, 0x00bf, 0x00a2, 0x00b2, 0x0095,
+    0x00b4, 0x00a6, 0x00c4, 0x00a8, 0x00c6, 0x00a9, 0x00c8, 0x00ab, 0x00ca, 0x00ad, 0x00cc, 0x00af, 0x00ce, 0x00b1, 0x00c1, 0x00a4,
+    0x00d1, 0x00b5, 0x00d3, 0x00b6, 0x00d5, 0x00b8, 0x00d7, 0x00ba, 0x00d9, 0x00bc, 0x00db, 0x00be, 0x00eb, 0x00c0, 0x00de, 0x00b3,
+    0x00e0, 0x00c3, 0x00e2, 0x00c5, 0x00e4, 0x00c7, 0x00e6, 0x00c9, 0x00e8, 0x00cb, 0x00f8, 0x00cd, 0x00fa, 0x00cf, 0x00ed, 0x00c2,
+    0x00ef, 0x00d2, 0x00f1, 0x00d4, 0x00f3, 0x00d6, 0x00f5, 0x00d8, 0x0105, 0x00da, 0x0107, 0x00dc, 0x0109, 0x00dd, 0x00fc, 0x00d0,
+    0x00fe, 0x00e1, 0x0100, 0x00e3, 0x0102, 0x00e5, 0x0112, 0x00e7, 0x0114, 0x00e9, 0x0116, 0x00ea, 0x0118, 0x00ec, 0x010b, 0x00df,
+    0x010d, 0x00f0, 0x010f, 0x00f2, 0x011f, 0x00f4, 0x0121, 0x00f6, 0x0123, 0x00f7, 0x0125, 0x00f9, 0x0127, 0x00fb, 0x011a, 0x00ee,
+    0x011c, 0x00ff, 0x012c, 0x0101, 0x012e, 0x0103, 0x0130, 0x0104, 0x0132, 0x0106, 0x0134, 0x0108, 0x0136, 0x010a, 0x0129, 0x00fd,
+    0x0139, 0x010e, 0x013b, 0x0110, 0x013d, 0x0111, 0x013f, 0x0113, 0x0141, 0x0115, 0x0143, 0x0117, 0x8139, 0x0119, 0x8139, 0x010c,
+    0x811d, 0x011d, 0x811d, 0x011e, 0x811d, 0x0120, 0x811d, 0x0122, 0x811d, 0x0124, 0x811d, 0x0126, 0x811d, 0x0128, 0x811d, 0x011b,
+    0x012b, 0x013a, 0x012d, 0x013c, 0x012f, 0x013e, 0x0131, 0x0140, 0x0133, 0x0142, 0x0135, 0x0144, 0x0137, 0x012a, 0x0138, 0x812b,
+};
+
 constexpr int FS = 41;                                // staged feature row stride (fp32 words)
 constexpr int FEAT_BYTES = ((102 * FS * 4 + 15) / 16) * 16;
 static_assert(FEAT_BYTES <= MAP_BYTES, "the feature map is staged inside the (idle) activation map");
 constexpr int RED_OFF = MAP_BYTES;                    // fp32 words from here on
 constexpr int BNT_WORDS = R8_LAYERS * 96;
 constexpr int NEXT_OFF = RED_OFF + (4 * 48 + 48 + BNT_WORDS) * 4;   // one word: the clip this workgroup takes next
-constexpr int X_LDS_BYTES = NEXT_OFF + 16;
+constexpr int POS_OFF = NEXT_OFF + 16;                // the position table (336 x 2 B)
+constexpr int X_LDS_BYTES = POS_OFF + 21 * 16 * 2;
 constexpr int KSTEPS = R8X_KSTEPS;                    // 14
 constexpr int A_STEP = 3 * 2 * 64;                    // u32x4 per k-step: [channel tile][part][lane]
 
@@ -81,6 +113,8 @@ __device__ __forceinline__ void store_split(char* lds, int addr, f32x4 v) {
     *reinterpret_cast<u32x2*>(lds + addr) = h;
     *reinterpret_cast<u32x2*>(lds + addr + PART_B) = m;
 }
+// byte offset (from a lane's cell in plane 0) of channels 16 m + 4 g .. + 3: channel block 2 m + (g >> 1), its upper or lower half
+__device__ __forceinline__ int st_off(int m, int g) { return (2 * m + (g >> 1)) * PLANE_B + 8 * (g & 1); }
 
 #define MF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
 // three-term product, small terms first
@@ -97,7 +131,8 @@ struct XCtx {
     float* mvec;
     const float* bnt;
     int tid, lane, w, g, pcol, mx;
-    int qb[6];   // byte address of this lane's cell (part 0, channel 0) in each of the wave's 6 position tiles
+    int qb[6];   // byte address of this lane's cell (part 0, channel block 0) in each of the wave's 6 position tiles
+    int padmask; // bit j: this lane of tile j is a pad lane (a clone of another lane: stored again, but counted once)
     bool xvalid;
 };
 
@@ -142,12 +177,12 @@ struct BFrag {
     u32x4 p[2];      // the two fp16 parts of one position tile's B fragment
 };
 
-// byte offset (within the map) of this lane's k-slot at k-step s: block bi = 4 s + g -> tap = bi / 6, channel block bi % 6
+// byte offset (from the lane's cell in plane 0) of this lane's k-slot at k-step s: block bi = 4 s + g -> tap = bi / 6, channel block bi % 6
 __device__ __forceinline__ int step_boff(int s, int g) {
     int bi = 4 * s + g;
     bi = bi < 54 ? bi : 53;   // blocks 54, 55 are zero-weight padding: re-read a valid block
     const int tap = bi / 6, cblk = bi - 6 * tap, ty = tap / 3, tx = tap - 3 * ty;
-    return ((ty - 1) * R8_RS + (tx - 1)) * CELL_B + cblk * 16;
+    return cblk * PLANE_B + ((ty - 1) * R8_RS + (tx - 1)) * 16;
 }
 __device__ __forceinline__ void load_a(AFrags& f, const u32x4* A, int s, int mx) {
     const u32x4* As = A + (size_t)s * A_STEP;
@@ -172,7 +207,8 @@ __device__ __forceinline__ void load_b(BFrag& b, const char* lds, int a0, int a1
         _Pragma("unroll") for (int j = 0; j < 6; ++j) {                               \
             BFrag& bcur = (j & 1) ? bb1 : bb0;                                        \
             BFrag& bnxt = (j & 1) ? bb0 : bb1;                                        \
-            if (j < 5) load_b(bnxt, c.lds, c.qb[j + 1] + (OA), c.qb[j + 1] + (OB));   \
+            if (R8H_ABLATE && (p.debug & 4)) {                                        \
+            } else if (j < 5) load_b(bnxt, c.lds, c.qb[j + 1] + (OA), c.qb[j + 1] + (OB));   \
             else load_b(bnxt, c.lds, c.qb[0] + (OA_NEXT), c.qb[0] + (OB_NEXT));       \
             __builtin_amdgcn_sched_barrier(0);                                        \
             if (j < 5) {                                                              \
@@ -196,6 +232,9 @@ __device__ __forceinline__ void load_b(BFrag& b, const char* lds, int a0, int a1
 #ifndef R8H_PREFETCH
 #define R8H_PREFETCH 1
 #endif
+#ifndef R8H_ABLATE      // 1: KWS_R8_DEBUG bits 4 / 8 drop the k-loops' LDS operand reads / weight loads (timing experiments; results are wrong)
+#define R8H_ABLATE 0
+#endif
 
 template <int TERMS, bool EVEN, bool LAST>
 __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int layer, int clip, f32x4 (&prev)[5][3],
@@ -210,7 +249,9 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
 
     const u32x4* A = reinterpret_cast<const u32x4*>(p.apk2) + (size_t)layer * R8H_ASTEPS * A_STEP + c.lane;
     AFrags fa1;
+    if (R8H_ABLATE) fa1 = fa0;
     BFrag bb0, bb1;   // ping-pong over position tiles; 6 tiles per step keeps the parity aligned across steps
+    if (R8H_ABLATE) bb1.p[0] = bb1.p[1] = (u32x4){0x3c003c00u, 0x38003800u, 0x3a003a00u, 0x34003400u};
     if (!R8H_PREFETCH) load_a(fa0, A, 0, mx);   // otherwise requested by the previous layer (or by the clip prologue)
     if (R8H_PRIO) __builtin_amdgcn_s_setprio(R8H_PRIO);
     load_b(bb0, c.lds, c.qb[0] + step_boff(0, g), c.qb[0] + step_boff(0, g) + PART_B);
@@ -220,10 +261,10 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
     {                                                                                                              \
         const int o0 = step_boff((S), g), o1 = step_boff((S) + 1, g),                                              \
                   o2 = step_boff((S) + 2 < KSTEPS ? (S) + 2 : KSTEPS - 1, g);                                      \
-        load_a(fa1, A, (S) + 1, mx);                                                                               \
+        if (!(R8H_ABLATE && (p.debug & 8))) load_a(fa1, A, (S) + 1, mx);                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         X_STEP(MFS0, o0, o0 + PART_B, o1, o1 + PART_B)                                                             \
-        load_a(fa0, A, (S) + 2 < KSTEPS ? (S) + 2 : KSTEPS - 1, mx); /* last one is a harmless re-read */          \
+        if (!(R8H_ABLATE && (p.debug & 8))) load_a(fa0, A, (S) + 2 < KSTEPS ? (S) + 2 : KSTEPS - 1, mx); /* last one is a harmless re-read */ \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         X_STEP(MFS1, o1, o1 + PART_B, o2, o2 + PART_B)                                                             \
     }
@@ -330,15 +371,17 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
-            for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + (16 * m + 4 * g) * 2, acc[j][m]);
-        if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, accx);
+            for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + st_off(m, g), acc[j][m]);
+        if (c.xvalid) store_split(c.lds, c.qb[5] + st_off(mx, g), accx);
         __syncthreads();
     } else {
 #pragma unroll
         for (int m = 0; m < 3; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = acc[0][m][r] + acc[1][m][r] + acc[2][m][r] + acc[3][m][r] + acc[4][m][r];
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) v += (c.padmask >> j) & 1 ? 0.f : acc[j][m][r];   // a pad lane's position is counted by the lane it clones
                 v += __shfl_xor(v, 8);
                 v += __shfl_xor(v, 4);
                 v += __shfl_xor(v, 2);
@@ -403,6 +446,8 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
     const int w = c.w, mx = c.mx;
 
     for (int i = threadIdx.x; i < BNT_WORDS; i += 256) bnt[i] = p.bn_tab[i];
+    unsigned short* const pos_tab = reinterpret_cast<unsigned short*>(ldsb + POS_OFF);
+    for (int i = threadIdx.x; i < 21 * 16; i += 256) pos_tab[i] = R8H_POS[i];
 
     // Clips are handed out by a device-wide counter, not by a fixed stride: the two workgroups of a CU do NOT progress at
     // the same rate (the SIMDs' arbiters favour the older waves: measured 84 against 106 us per clip, so with a static
@@ -427,16 +472,18 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         c.g = c.lane >> 4;
         c.pcol = c.lane & 15;
         const int g = c.g, pcol = c.pcol, lane = c.lane;
+        c.padmask = 0;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int nt = j < 5 ? 5 * w + j : 20;
-            const int n = 16 * nt + pcol;
-            const int nn = n < R8_NPOS ? n : R8_NPOS - 1;
+            const int e = pos_tab[16 * nt + pcol];
+            const int nn = e & 0x7fff;
             const int y = nn / W8_W;
             const int x = nn - y * W8_W;
-            c.qb[j] = ((y + 1) * R8_RS + x + 1) * CELL_B;
+            c.qb[j] = ((y + 1) * R8_RS + x + 1) * 16;
+            c.padmask |= (e >> 15) << j;
         }
-        c.xvalid = w < 3 && (16 * 20 + pcol) < R8_NPOS;
+        c.xvalid = w < 3 && !((c.padmask >> 5) & 1);
 
         // ---- stage the (101, 40) feature map as fp32 with a zero top row / left column, inside the idle map region
         {
@@ -484,8 +531,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int nt = j < 5 ? 5 * w + j : 20;
-                const int n = 16 * nt + pcol;
-                const int nn = n < R8_NPOS ? n : R8_NPOS - 1;
+                const int nn = pos_tab[16 * nt + pcol] & 0x7fff;
                 const int y = nn / W8_W;
                 const int x = nn - y * W8_W;
                 lbw[j] = (4 * y * FS + 3 * x + (g == (TERMS >= 3 ? 3 : 1) ? 2 * FS + 2 : 0)) * 4;
@@ -625,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         for (int t = tid; t < 59 * 12; t += 256) {
             const int hc = t / 12, sub = t - 12 * hc;
             const int cell = hc < 14 ? hc : (hc < 39 ? R8_RS * (hc - 13) : R8_RS * 26 + (hc - 39));
-            *reinterpret_cast<u32x4*>(ldsb + (sub / 6) * PART_B + cell * CELL_B + (sub % 6) * 16) = (u32x4){0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(ldsb + (sub / 6) * PART_B + (sub % 6) * PLANE_B + cell * 16) = (u32x4){0u, 0u, 0u, 0u};
         }
         shift = __builtin_amdgcn_readfirstlane(range_shift(guard_read(reinterpret_cast<const unsigned*>(c.red))));
         if (shift > 0) {   // (wave-uniform, never taken for trained models)
@@ -634,14 +680,14 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
-                for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + (16 * m + 4 * g) * 2, prev[j][m] * down);
-            if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, prevx * down);
+                for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + st_off(m, g), prev[j][m] * down);
+            if (c.xvalid) store_split(c.lds, c.qb[5] + st_off(mx, g), prevx * down);
         } else {
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
-                for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + (16 * m + 4 * g) * 2, prev[j][m]);
-            if (c.xvalid) store_split(c.lds, c.qb[5] + (16 * mx + 4 * g) * 2, prevx);
+                for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + st_off(m, g), prev[j][m]);
+            if (c.xvalid) store_split(c.lds, c.qb[5] + st_off(mx, g), prevx);
         }
         __syncthreads();
 

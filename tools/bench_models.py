@@ -22,7 +22,8 @@ MFLOP = {"resnet__res8": 74.35, "resnet__res8_narrow": 14.05, "resnet__res15": 1
 
 
 def main():
-    dtype = os.environ.get("KWS_BENCH_DTYPE", "f32")      # f32 (fp32-accurate bf16x6) | bf16x3 | bf16
+    dtype = os.environ.get("KWS_BENCH_DTYPE", "f32")      # f32 (fp32-accurate, three-term fp16 products) | bf16x3 | bf16 | fp16
+    peak = {"f32": 2516.0 / 3, "bf16x3": 2516.0 / 3, "bf16": 2516.0, "fp16": 2516.0}[dtype]   # TFLOP/s roof of the dtype's arithmetic
     only = sys.argv[1:] or None
     dev = torch.device("cuda:0")
     for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "model_*.npz"))):
@@ -41,7 +42,7 @@ def main():
                 sd[k] = 0.25 + 0.5 * torch.rand_like(v)
         model.load_state_dict(sd)
         model = model.to(dev).eval()
-        batch = 8192 if MFLOP[tag] < 400 else 2048
+        batch = int(os.environ.get("KWS_BENCH_BATCH", "0")) or (8192 if MFLOP[tag] < 400 else 2048)
         x = torch.randn(batch, 101, 40, device=dev) * 2.5 + 0.65
         model(x[:64])
         torch.cuda.synchronize()
@@ -54,7 +55,7 @@ def main():
         cps = batch / dt
         print(json.dumps({"model": tag, "plan": model.plan_name(), "dtype": dtype, "batch": batch, "ms": round(dt * 1e3, 2),
                           "clips_per_s": round(cps), "TFLOPs_alg": round(cps * MFLOP[tag] * 1e6 / 1e12, 2),
-                          "frac_fp32_peak": round(cps * MFLOP[tag] * 1e6 / 157.3e12, 3)}), flush=True)
+                          "frac_of_roof": round(cps * MFLOP[tag] * 1e6 / 1e12 / peak, 3), "roof_TFLOPs": round(peak, 1)}), flush=True)
         del model
         torch.cuda.empty_cache()
 

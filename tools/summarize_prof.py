@@ -9,7 +9,7 @@ import os
 import sys
 
 
-def main(src, tag, dst="profiles/r01"):
+def main(src, tag, dst="profiles/r02"):
     os.makedirs(dst, exist_ok=True)
     summary = {}
     for path in glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True):
