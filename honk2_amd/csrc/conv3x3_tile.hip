@@ -131,13 +131,13 @@ __device__ __forceinline__ void split4_f16(f32x4 x, u32x2 (&out)[2]) {
 // arrive scaled by 2^S, the accumulator is scaled back in the epilogue's FMA); the LDS cell shrinks to 2 x NB*8 x 2 B, which
 // buys 320-position tiles (5 per wave).  Otherwise bf16 parts with TERMS = 6 / 3 / 1 products (reduced-precision dtypes).
 template <int NB, int MT, int TERMS, bool F16>
-__global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) {
+__global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_kernel(TileConvParams p) {
     constexpr int LP = F16 ? 2 : 3;                 // parts per LDS cell / per weight fragment group
     constexpr int CELL = NB * 16 * LP, PART = NB * 16;
     constexpr int GCELL = NB * 32;                  // global cell: NB*8 channels x 4 B
     constexpr int STEPS = (9 * NB + 3) / 4;
     constexpr int NP = F16 ? (TERMS >= 3 ? 2 : 1) : (TERMS == 6 ? 3 : (TERMS == 3 ? 2 : 1));   // parts that take part in the products
-    constexpr int TILE_P = F16 ? T3_TILE_P_F16 : T3_TILE_P;
+    constexpr int TILE_P = t3_tile_positions(F16, NB);
     constexpr int JT = TILE_P / 64;                 // position tiles per wave (5 / 3)
     constexpr int NQ = NB * 2;         // 4-channel quads per cell
     constexpr int NGRP = 256 / NQ;     // cells copied per pass (21 / 42)
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
     // residual values of this lane's outputs: requested now, consumed in the epilogue
     f32x4 resv[JT][MT];
     const char* const resp = reinterpret_cast<const char*>(p.res);
-    if (resp) {
+    if (resp && !(p.debug & 8)) {
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             const size_t rcell = (size_t)layout_cell(ob[j], oy[j], ox[j], p.ld_res, p.H, p.W) * GCELL;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
                     // Cells outside the tensor or in the padding of a sub-map are never tapped (tmask above), so whatever
                     // is copied for them is irrelevant: the address is clamped instead of tested.
                     const int q = min(max(P0 - Ws - 1 + i0 + u * NGRP, 0), p.total - 1);
-                    v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)q * GCELL + qd * 16);
+                    v[u] = (p.debug & 2) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * GCELL + qd * 16);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
     int tap_c, off_c = step_off(0, tap_c);
     TLOADA(a0, 0)
     TLOADB(bb0, b_addr(0, tap_c, off_c))
-    for (int s = 0; s < STEPS; s += 2) {
+    for (int s = (p.debug & 1) ? STEPS : 0; s < STEPS; s += 2) {
         int tap_n, off_n = step_off(s + 1, tap_n);
         if (s + 1 < STEPS) TLOADA(a1, s + 1)
         __builtin_amdgcn_sched_barrier(0);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
                 v[r] = co0 + r < p.Cout ? x : 0.f;   // padded channels hold exact zeros
                 amax = fmaxf(amax, fabsf(v[r]));
             }
-            *reinterpret_cast<f32x4*>(outp + ocell + co0 * 4) = v;
+            if (!(p.debug & 4)) *reinterpret_cast<f32x4*>(outp + ocell + co0 * 4) = v;
         }
     }
     range_note(p.rg, amax);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(TileConvParams p) 
 
 // one tile buffer (TILE_P + 2 Ws + 2 cells + the zero cell)
 size_t conv3x3_tile_lds_bytes(int cp, int Ws, bool f16) {
-    return (size_t)((f16 ? T3_TILE_P_F16 : T3_TILE_P) + 2 * Ws + 3) * cp * (f16 ? 4 : 6);
+    return (size_t)(t3_tile_positions(f16, cp / 8) + 2 * Ws + 3) * cp * (f16 ? 4 : 6);
 }
 
 bool conv3x3_tile_supported(int C, int Cout, int Ws) {
@@ -352,7 +352,7 @@ bool conv3x3_tile_supported(int C, int Cout, int Ws) {
 
 template <int NB, int MT, int TERMS, bool F16>
 static hipError_t launch_t3k(const TileConvParams& p, hipStream_t s) {
-    constexpr int tile = F16 ? T3_TILE_P_F16 : T3_TILE_P;
+    constexpr int tile = t3_tile_positions(F16, NB);
     const unsigned grid = (unsigned)((p.total + tile - 1) / tile);
     const size_t lds = conv3x3_tile_lds_bytes(NB * 8, p.Ws, F16);
     auto k = conv3x3_tile_kernel<NB, MT, TERMS, F16>;

@@ -632,6 +632,8 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                 tp.Hs = (sh.H + dd - 1) / dd; tp.Ws = (sh.W + dd - 1) / dd;
                 tp.total = nb * dd * dd * tp.Hs * tp.Ws;
                 tp.rg = rg;
+                static const int t3_dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
+                tp.debug = t3_dbg;
                 HIP_TRY(launch_conv3x3_tile(tp, C, s));
                 if (even) {
                     std::swap(xc, xn);

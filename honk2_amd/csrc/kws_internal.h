@@ -272,7 +272,9 @@ void pack_conv_weights_f16x3(const ConvGeom& g, const float* w, float scale, std
 // LDS-tiled 3x3 "same" conv with power-of-two dilation over channels-last fp32 tensors in sub-map layouts
 // (conv3x3_tile.hip)
 constexpr int T3_TILE_P = 192;         // bf16 parts (reduced-precision dtypes): 3 position tiles per wave
-constexpr int T3_TILE_P_F16 = 320;     // fp16 parts (default): 5 position tiles per wave
+constexpr int T3_TILE_P_F16 = 320;     // fp16 parts (default), 41-48 channels: 5 position tiles per wave, two workgroups per CU
+constexpr int T3_TILE_P_F16_NARROW = 192;   // fp16 parts, 17-24 channels: 3 tiles per wave, three workgroups per CU (+14 % measured)
+constexpr int t3_tile_positions(bool f16, int nb) { return f16 ? (nb <= 3 ? T3_TILE_P_F16_NARROW : T3_TILE_P_F16) : T3_TILE_P; }
 struct TileConvParams {
     const float* in;       // CL tensor in layout(2^ld_in): [clip][y mod d][x mod d][ceil(H/d)][ceil(W/d)][cp] fp32
     float* out;            // CL tensor, written in layout(2^ld_out)
@@ -287,6 +289,8 @@ struct TileConvParams {
     int f16;               // 1: two-part fp16 operands, three terms (fp32-accurate default)
     float inv_scale;       // 2^-S of the fp16 weights (1 for bf16)
     RangeGate rg;          // fp16 range guard (zero-initialised: none)
+    int debug;             // KWS_T3_DEBUG, timing experiments only (results are wrong when set): 1 skip the k-loop, 2 skip the
+                           // staging loads, 4 skip the output stores, 8 skip the residual read
 };
 bool conv3x3_tile_supported(int C, int Cout, int Ws);
 void pack_conv3x3_tile_weights_f16(int C, const float* w /*C,C,3,3*/, float scale, std::vector<unsigned short>& dst);

@@ -416,11 +416,12 @@ size_t res8h_lds_bytes() { return (size_t)X_LDS_BYTES; }
 // Two workgroups (two clips) per CU: 77 KB of LDS and <= 256 registers each.  While one is in an epilogue, in conv_0 or
 // waiting for its features, the other's waves use the matrix pipe -- the overlap a single workgroup with one wave per SIMD
 // cannot have.  Measured (KWS_R8_WGS_PER_CU=1|2 with this very kernel): 21.9 -> 16.9 ms per 65 536 clips; the one-wave-
-// per-SIMD, 502-register build of the same code took 18.0 ms.  The overlap is partial because at 256 registers hipcc emits
-// VGPR-accumulator MFMAs, which one wave can only issue at half rate (tools/mfma_dep_probe.cpp): alone in its k-loop a
-// workgroup does not fill the pipe.  Forcing AGPR accumulators splits the budget 128 / 128 and spills (18.2 ms); a
-// start-up stagger of the second workgroup changes nothing (re-checked in v8 with the second workgroup identified per
-// physical CU -- HW_ID / XCC_ID arrival counters -- and delays of 30 / 60 / 90 k ticks: 13.62 - 13.76 ms, noise).
+// per-SIMD, 502-register build of the same code took 18.0 ms.  The accumulator file is not what limits the overlap (a lone
+// wave issues an MFMA every 17 clocks with VGPR or AGPR accumulators: tools/mfma_acc_probe.cpp); the two workgroups of a CU
+// simply do not run at the same speed (84 against 106 us per clip: the arbiters favour the older waves), hence the clip
+// queue below, and the kernel as a whole is clock-limited.  A start-up stagger of the second
+// workgroup changes nothing (v8: second workgroup identified per physical CU -- HW_ID / XCC_ID arrival counters -- and
+// delays of 30 / 60 / 90 k ticks: 13.62 - 13.76 ms, noise).
 // phase timestamps for tools/r8_phases.py: build with -DR8H_TIMING (they overwrite the consumed feature rows)
 #ifdef R8H_TIMING
 #define R8H_TS_DECL unsigned long long ts[8], rt0 = __builtin_amdgcn_s_memrealtime();
