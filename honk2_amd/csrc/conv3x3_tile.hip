@@ -457,6 +457,67 @@ hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, i
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ conv_0 straight to CL
+// conv_0 (1 -> C, 3x3, pad 1, no bias) + ReLU [+ AvgPool(kh, kw), stride = window, floor] of a ResNet (reference
+// model/resnet.py:40-44), written directly as the channels-last fp32 tensor the tiled layers read: one thread = one (pooled) output
+// position x four channels, plain fp32 FMAs over the 3 x 3 taps of every window member (1.6 MFLOP per clip: the pass is bound by
+// its 0.8 MB per clip of output, not by arithmetic).  Replaces conv_igemm_kernel (NCHW out, 0.41 ms per 1 024 res15 clips at 1.6
+// TB/s) + nchw_to_cl_kernel (0.29 - 0.56 ms).  Lanes run quad-fastest, so the 12 lanes of a position read the same input words.
+__global__ __launch_bounds__(256) void conv0_cl_kernel(const float* __restrict__ feat, const float* __restrict__ w9 /*[9][cp]*/,
+                                                       float* __restrict__ out, long long total, int T, int F, int Hp, int Wp,
+                                                       int kh, int kw, int cp, RangeGate rg) {
+    if (range_gate_closed(rg)) return;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int nq = cp / 4;
+    const int q = (int)(i % nq);
+    long long t = i / nq;
+    const int ox = (int)(t % Wp);
+    t /= Wp;
+    const int oy = (int)(t % Hp);
+    const long long b = t / Hp;
+    f32x4 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f32x4*>(w9 + k * cp + 4 * q);
+    const float* src = feat + b * (long long)T * F;
+    f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int my = 0; my < kh; ++my)
+        for (int mx = 0; mx < kw; ++mx) {
+            const int y = oy * kh + my, x = ox * kw + mx;
+            f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = y + ky - 1, xx = x + kx - 1;
+                    const float v = (yy >= 0 && yy < T && xx >= 0 && xx < F) ? src[yy * F + xx] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[r] = fmaf(w[3 * ky + kx][r], v, c[r]);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[r] += fmaxf(c[r], 0.f);
+        }
+    if (kh * kw > 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = sum[r] / (float)(kh * kw);   // a true division, as nn.AvgPool2d's sum / count
+    }
+    *reinterpret_cast<f32x4*>(out + ((b * Hp + oy) * (long long)Wp + ox) * cp + 4 * q) = sum;
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(sum[r]));
+    range_note(rg, amax);
+}
+
+hipError_t launch_conv0_cl(const float* feat, const float* w9, float* out, int B, int T, int F, int kh, int kw, int cp,
+                           hipStream_t s, RangeGate rg) {
+    const int Hp = T / kh, Wp = F / kw;
+    const long long total = (long long)B * Hp * Wp * (cp / 4);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(conv0_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, w9, out, total, T, F, Hp, Wp,
+                       kh, kw, cp, rg);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ mean + linear on CL
 // ResNet tail (reference model/resnet.py:57-59), last BatchNorm folded in: mean(BN(x)) == BN(mean(x)).
 // One workgroup per clip; x is (B, HW, cp) fp32 in layout(1).

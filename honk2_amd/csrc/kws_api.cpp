@@ -59,7 +59,7 @@ enum LwMode { LW_FP32 = 0, LW_NCHW = 1, LW_TILED = 2 };
 
 struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the layer-wise plans
     ConvGeom g{};           // B/H/W/Ho/Wo filled per call for ResNet, at create for CNN
-    DevMem apk, apk16, apk16h, apk_t3h, bias, border, border_pad;   // apk16h: fp16 fragments of the generic kernel
+    DevMem apk, apk16, apk16h, apk_t3h, bias, border, border_pad, w9cl;   // apk16h: fp16 fragments of the generic kernel; w9cl: conv_0 as [9 taps][C padded to 8] (conv0_cl_kernel)
     float x_scale = 1.f;     // 2^S of apk16h   // apk_t3h: fp16 fragments of the tiled 3x3 kernel
     float t3h_scale = 1.f;   // 2^S of apk_t3h   // border_pad: rows padded to a multiple of 8 channels (tiled kernel)
     bool has_bias = false, has_border = false, use_x = false;   // use_x: bf16x6 kernel available for this layer
@@ -418,6 +418,13 @@ int finalize(kws_handle* h) {
                 L.has_border = true;
             }
             if ((rc = upload_packed(L, wf.data(), h->lw_mode))) return rc;
+            if (i == 0 && h->lw_mode == LW_TILED && conv3x3_tile_supported(C, C, 1)) {
+                const int cp = (C + 7) / 8 * 8;
+                std::vector<float> w9((size_t)9 * cp, 0.f);
+                for (int co = 0; co < C; ++co)
+                    for (int t9 = 0; t9 < 9; ++t9) w9[(size_t)t9 * cp + co] = L.w_host[(size_t)co * 9 + t9];
+                if ((rc = L.w9cl.upload(w9.data(), w9.size() * 4))) return rc;
+            }
             if (i >= 1 && h->lw_mode == LW_TILED && conv3x3_tile_supported(C, C, 1)) {
                 std::vector<unsigned short> pk;
                 L.t3h_scale = weight_scale_pow2(wf.data(), wf.size());
@@ -542,10 +549,10 @@ size_t act_bytes(const kws_handle* h, int B, int T) {
         if (use_fused(h, T)) return 0;
         const ResnetShape s = resnet_shape(h, T);
         const size_t full = (size_t)s.C * s.T * s.F, small = (size_t)s.C * s.H * s.W;
-        if (resnet_tiled(h, s)) {   // conv_0 output (fp32 NCHW) + three channels-last tensors
+        if (resnet_tiled(h, s)) {   // three channels-last tensors (conv_0 writes the first one directly)
             const size_t cl = resnet_cl_cells(h, s) * pad8(s.C);
             const int cb = tiled_chunk(h, s, B);
-            return align256(full * cb * 4) + 3 * align256(cl * cb * 4) + align256((size_t)8 * s.T * s.F * 4 + 4096);
+            return 3 * align256(cl * cb * 4) + align256((size_t)8 * s.T * s.F * 4 + 4096);
         }
         const int cb = chunk_clips(full, B);
         // + slack: padded channel blocks of the last clip read (and discard) up to 7 planes past a tensor's end
@@ -595,22 +602,18 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
     const kws_model_desc& d = h->d;
     const ResnetShape sh = resnet_shape(h, T);
     const int C = sh.C, cp = pad8(C);
-    const size_t full = (size_t)C * sh.T * sh.F, cl = resnet_cl_cells(h, sh) * cp;
+    const size_t cl = resnet_cl_cells(h, sh) * cp;
     const int cb = tiled_chunk(h, sh, B);
-    float* bufA = (float*)ws; ws += align256(full * cb * 4);
     float* X = (float*)ws; ws += align256(cl * cb * 4);
     float* X2 = (float*)ws; ws += align256(cl * cb * 4);
     float* Y = (float*)ws;
     int rc;
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
-        // conv_0 runs on the fp32-input MFMA: no fp16 operands, one launch serves both passes (bufA is not overwritten)
-        ConvGeom g0 = h->rconv[0].g;
-        set_spatial(g0, nb, sh.T, sh.F);
-        ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, bufA, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr, nullptr};
-        if ((rc = launch_layer(h->rconv[0], g0, a0, s, dtype_terms(d.dtype)))) return rc;
         auto pass = [&](int terms, RangeGate rg) -> int {
-            HIP_TRY(launch_nchw_to_cl(bufA, X, nb, C, sh.T, sh.F, sh.pooled ? d.pool_h : 1, sh.pooled ? d.pool_w : 1, 0, cp, s, rg));
+            // conv_0 + ReLU (+ AvgPool) in plain fp32, straight into the channels-last tensor
+            HIP_TRY(launch_conv0_cl(feat + (size_t)b0 * sh.T * sh.F, h->rconv[0].w9cl.as<float>(), X, nb, sh.T, sh.F,
+                                    sh.pooled ? d.pool_h : 1, sh.pooled ? d.pool_w : 1, cp, s, rg));
             float* xc = X;
             float* xn = X2;
             int ld_x = 0;   // layout of xc

@@ -298,6 +298,9 @@ hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
 // fp32 (B, C, H, W) -> pooled (stride = window, floor; 1 x 1 = transpose only) channels-last (B, H/kh, W/kw, cp) fp32
 hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, int W, int kh, int kw, int is_max, int cp,
                              hipStream_t s, RangeGate rg = RangeGate{nullptr, 0});
+// conv_0 (3x3, pad 1) + ReLU [+ AvgPool(kh, kw)] of a ResNet straight into the channels-last fp32 tensor; w9 = weights as [9 taps][cp]
+hipError_t launch_conv0_cl(const float* feat, const float* w9, float* out, int B, int T, int F, int kh, int kw, int cp,
+                           hipStream_t s, RangeGate rg = RangeGate{nullptr, 0});
 hipError_t launch_mean_linear_cl(const float* x, float* logits, int B, int C, int cp, int HW, const float* mean,
                                  const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s,
                                  RangeGate rg = RangeGate{nullptr, 0});
