@@ -36,6 +36,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef int int2_ __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -76,13 +78,6 @@ __device__ __forceinline__ int fdiv(int q, int dv, float inv, int& rem) {
     }
     rem = r;
     return t;
-}
-
-// cell index of image position (b, y, x) in layout(2^ld) of an H x W map
-__device__ __forceinline__ int layout_cell(int b, int y, int x, int ld, int H, int W) {
-    const int d = 1 << ld, Hs = (H + d - 1) >> ld, Ws = (W + d - 1) >> ld;
-    const int sub = ((y & (d - 1)) << ld) | (x & (d - 1));
-    return (((b << (2 * ld)) + sub) * Hs + (y >> ld)) * Ws + (x >> ld);
 }
 
 // two fp16 parts (x = h + l to 22 bits) of four fp32 values: one packed convert + one mixed-precision FMA per value
@@ -144,6 +139,13 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
     constexpr int UNR = NB == 6 ? 10 : 5;  // staging passes in flight together
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
+#ifdef T3_TIMING   // 100 MHz wall-clock stamps of this workgroup's phases (tools/t3_phases.py)
+    unsigned long long t3ts[12];
+#define T3_TS(i) t3ts[i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define T3_TS(i)
+#endif
+    T3_TS(0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -152,64 +154,55 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
     const int pcol = lane & 15;
     const int ld = p.ld_in, d = 1 << ld, dmask = d - 1;
     const int Hs = p.Hs, Ws = p.Ws;
+    T3_TS(9)
     const int P0 = (int)blockIdx.x * TILE_P;
     const int ncell = TILE_P + 2 * Ws + 2;
     const int zero_off = ncell * CELL;
     const float inv_ws = 1.0f / (float)Ws, inv_hs = 1.0f / (float)Hs;
 
-    // ---------------------------------------------------------------- this lane's three output positions
-    int lbase[JT], tmask[JT], ob[JT], oy[JT], ox[JT];
-    bool valid[JT];
+    // ---------------------------------------------------------------- this lane's output positions: one table entry each
+    int lbase[JT], tmask[JT], ocl[JT], rcl[JT];   // tmask: tap mask | border class << 9 | valid << 13; ocl / rcl: output / residual cell
+    const float inv_cpc = 1.0f / (float)p.cpc_in;
+    (void)inv_ws; (void)inv_hs; (void)dmask; (void)Hs;
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         const int local = (w * JT + j) * 16 + pcol;
-        const int P = P0 + local;
-        int xs, ys;
-        const int t = fdiv(P, Ws, inv_ws, xs);
-        const int m = fdiv(t, Hs, inv_hs, ys);
-        const int sub = m & (d * d - 1);
-        ob[j] = m >> (2 * ld);
-        oy[j] = (ys << ld) + (sub >> ld);
-        ox[j] = (xs << ld) + (sub & dmask);
-        valid[j] = P < p.total && oy[j] < p.H && ox[j] < p.W;
-        // a tap is live when it stays inside the sub-map AND lands on a real image position (sub-maps are padded to a
-        // common size; the padding and everything outside the tensor is never read as an operand)
-        const int r0 = sub >> ld, c0 = sub & dmask;
-        int rowok = 0, colok = 0;
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            const int yy = ys + kk - 1, xx = xs + kk - 1;
-            if (yy >= 0 && yy < Hs && (yy << ld) + r0 < p.H) rowok |= 1 << kk;
-            if (xx >= 0 && xx < Ws && (xx << ld) + c0 < p.W) colok |= 1 << kk;
-        }
-        int mk = 0;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-            if ((rowok >> ky) & 1) mk |= colok << (3 * ky);
-        tmask[j] = mk;
+        const int P = min(P0 + local, p.total - 1);
+        int q;
+        const int b = fdiv(P, p.cpc_in, inv_cpc, q);
+        const i32x4 e = *reinterpret_cast<const i32x4*>(p.postab + 4 * q);
+        tmask[j] = P0 + local < p.total ? e[0] : 0;
+        ocl[j] = b * p.cpc_out + e[1];
+        rcl[j] = b * p.cpc_res + e[2];
         lbase[j] = (local + Ws + 1) * CELL;
     }
-
+    T3_TS(8)
     // residual values of this lane's outputs: requested now, consumed in the epilogue
     f32x4 resv[JT][MT];
     const char* const resp = reinterpret_cast<const char*>(p.res);
     if (resp && !(p.debug & 8)) {
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
-            const size_t rcell = (size_t)layout_cell(ob[j], oy[j], ox[j], p.ld_res, p.H, p.W) * GCELL;
+            const size_t rcell = (size_t)rcl[j] * GCELL;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int co0 = m * 16 + 4 * g;
                 resv[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (valid[j] && co0 < NB * 8) resv[j][m] = *reinterpret_cast<const f32x4*>(resp + rcell + co0 * 4);
+                if (((tmask[j] >> 13) & 1) && co0 < NB * 8) resv[j][m] = *reinterpret_cast<const f32x4*>(resp + rcell + co0 * 4);
             }
         }
     }
 
+    T3_TS(1)
     // ---------------------------------------------------------------- stage cells [P0 - Ws - 1, P0 + TILE_P + Ws + 1)
     {
         const int qd = tid % NQ, grp = tid / NQ;
         if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + zero_off + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+        if (tid < 4 * (STEPS + 2)) {   // k-step table (see the k-loop): entry [s][g], two spare steps for the look-ahead
+            const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
+            // (zero-weight padding blocks, tap >= 9, test bit 31 of the mask word, which is never set: they read the zero cell)
+            reinterpret_cast<int2_*>(lds + zero_off + CELL)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16 - zero_off, tap < 9 ? tap : 31};
+        }
         if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
             for (int i0 = grp; i0 < ncell; i0 += UNR * NGRP) {
@@ -241,7 +234,9 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
             }
         }
     }
+    T3_TS(2)
     __syncthreads();
+    T3_TS(3)
 
     const u32x4* A = reinterpret_cast<const u32x4*>(p.apk16) + lane;
 
@@ -251,17 +246,16 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // this lane group's K block at k-step s: bi = 4 s + g -> (tap, channel block); returns the tap and the byte offset
-    // of (tap, block) relative to the centre cell
-    auto step_off = [&](int s, int& tap) {
-        const int bi = 4 * s + g;
-        tap = bi / NB;
-        const int cblk = bi - tap * NB;
-        const int ty = tap / 3, tx = tap - 3 * ty;
-        return ((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16;
-    };
-    auto b_addr = [&](int j, int tap, int off) {
-        return ((tmask[j] >> tap) & 1) ? lbase[j] + off : zero_off;   // tap >= 9 (zero-weight padding blocks): bit clear
+    // This lane group's K block at k-step s: bi = 4 s + g -> (tap, channel block).  (tap, byte offset of that tap and block relative
+    // to the centre cell, minus zero_off) comes from a small LDS table written once per workgroup -- computing it in the loop cost
+    // two integer divisions per step and, with a five-instruction select per fragment address, 146 vector instructions per k-step
+    // against 45 MFMAs: the k-loop was bound by its own address arithmetic (11 us per tile where the MFMAs need 5).
+    // A tap that leaves the sub-map or the tensor (mask bit clear; always for the zero-weight padding blocks, tap >= 9) reads the
+    // shared zero cell: address = zero_off + ((lbase + offz) & -(bit)).
+    const int2_* const ktab = reinterpret_cast<const int2_*>(lds + zero_off + CELL) + g;
+    auto b_addr = [&](int j, int2_ e) {
+        const int m = __builtin_amdgcn_sbfe(tmask[j], e[1], 1);      // 0 or -1
+        return zero_off + ((lbase[j] + e[0]) & m);
     };
 #define TLOADB(BR, ADDR)                                                                              \
     {                                                                                                 \
@@ -275,12 +269,12 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
     }
     // one k-step: B fragments are fetched one position tile ahead (tile 0 of the next step during the last tile); BX / BY
     // are the two fragment buffers, BX holding tile 0 on entry; JT is odd, so BY holds the next step's tile 0 on exit
-#define TSTEP(AR, BX, BY, OFFN, TAPN)                                                                 \
+#define TSTEP(AR, BX, BY, TAPN)                                                                       \
     {                                                                                                 \
         _Pragma("unroll") for (int j = 0; j < JT; ++j) {                                              \
             u32x4 (&cur_)[NP] = (j & 1) ? BY : BX;                                                    \
             u32x4 (&nxt_)[NP] = (j & 1) ? BX : BY;                                                    \
-            TLOADB(nxt_, j + 1 < JT ? b_addr(j + 1, tap_c, off_c) : b_addr(0, TAPN, OFFN))            \
+            TLOADB(nxt_, j + 1 < JT ? b_addr(j + 1, e_c) : b_addr(0, TAPN))                           \
             __builtin_amdgcn_sched_barrier(0);                                                        \
             _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], cur_, acc[j][m]) }           \
             __builtin_amdgcn_sched_barrier(0);                                                        \
@@ -289,37 +283,36 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
     static_assert(JT % 2 == 1, "the fragment buffers swap roles every k-step");
 
     u32x4 a0[MT][NP], a1[MT][NP], bb0[NP], bb1[NP];
-    int tap_c, off_c = step_off(0, tap_c);
+    if (p.debug & 16) TLOADA(a1, 1)   // (timing experiment: the k-loop then re-uses the first two steps' weight fragments)
+    int2_ e_c = ktab[0];
     TLOADA(a0, 0)
-    TLOADB(bb0, b_addr(0, tap_c, off_c))
+    TLOADB(bb0, b_addr(0, e_c))
     for (int s = (p.debug & 1) ? STEPS : 0; s < STEPS; s += 2) {
-        int tap_n, off_n = step_off(s + 1, tap_n);
-        if (s + 1 < STEPS) TLOADA(a1, s + 1)
+        int2_ e_n = ktab[4 * (s + 1)];
+        if (s + 1 < STEPS && !(p.debug & 16)) TLOADA(a1, s + 1)
         __builtin_amdgcn_sched_barrier(0);
-        TSTEP(a0, bb0, bb1, off_n, tap_n)
+        TSTEP(a0, bb0, bb1, e_n)
         if (s + 1 >= STEPS) break;
-        tap_c = tap_n;
-        off_c = off_n;
-        off_n = step_off(s + 2, tap_n);
-        if (s + 2 < STEPS) TLOADA(a0, s + 2)
+        e_c = e_n;
+        e_n = ktab[4 * (s + 2)];
+        if (s + 2 < STEPS && !(p.debug & 16)) TLOADA(a0, s + 2)
         __builtin_amdgcn_sched_barrier(0);
-        TSTEP(a1, bb1, bb0, off_n, tap_n)
-        tap_c = tap_n;
-        off_c = off_n;
+        TSTEP(a1, bb1, bb0, e_n)
+        e_c = e_n;
     }
 #undef TLOADB
 #undef TLOADA
 #undef TSTEP
 
+    T3_TS(4)
     // ---------------------------------------------------------------- epilogue
     char* const outp = reinterpret_cast<char*>(p.out);
     float amax = 0.f;   // largest magnitude stored (fp16 range guard)
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-        if (!valid[j]) continue;
-        const int bmask = (oy[j] - d >= 0 ? 1 : 0) | (oy[j] + d < p.H ? 2 : 0) | (ox[j] - d >= 0 ? 4 : 0) |
-                          (ox[j] + d < p.W ? 8 : 0);
-        const size_t ocell = (size_t)layout_cell(ob[j], oy[j], ox[j], p.ld_out, p.H, p.W) * GCELL;
+        if (!((tmask[j] >> 13) & 1)) continue;
+        const int bmask = (tmask[j] >> 9) & 15;
+        const size_t ocell = (size_t)ocl[j] * GCELL;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int co0 = m * 16 + 4 * g;
@@ -337,11 +330,23 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
         }
     }
     range_note(p.rg, amax);
+#ifdef T3_TIMING
+    T3_TS(5)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    T3_TS(6)
+    if (p.dbg_ts && tid == 0 && blockIdx.x < 8192) {     // wave 0 only: 32 words per workgroup
+        unsigned long long* o = p.dbg_ts + (size_t)blockIdx.x * 32;
+        for (int i = 0; i < 7; ++i) o[i] = t3ts[i];
+        o[8] = t3ts[8];
+        o[9] = t3ts[9];
+        o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    }
+#endif
 }
 
 // one tile buffer (TILE_P + 2 Ws + 2 cells + the zero cell)
 size_t conv3x3_tile_lds_bytes(int cp, int Ws, bool f16) {
-    return (size_t)(t3_tile_positions(f16, cp / 8) + 2 * Ws + 3) * cp * (f16 ? 4 : 6);
+    return (size_t)(t3_tile_positions(f16, cp / 8) + 2 * Ws + 3) * cp * (f16 ? 4 : 6) + 512;   // + the k-step table
 }
 
 bool conv3x3_tile_supported(int C, int Cout, int Ws) {
@@ -405,6 +410,38 @@ void pack_conv3x3_tile_weights_f16(int C, const float* w, float scale, std::vect
                     dst[((((size_t)s * mt + m) * 2 + 1) * 64 + lane) * 8 + e] = l;
                 }
             }
+}
+
+// Per-cell metadata of one clip (see TileConvParams::postab): the decode the kernel used to do per position and tile
+void build_tile_conv_table(int H, int W, int ld_in, int ld_out, int ld_res, std::vector<int>& tab, int& cpc_in, int& cpc_out, int& cpc_res) {
+    auto cells = [&](int ld) { const int d = 1 << ld; return d * d * ((H + d - 1) >> ld) * ((W + d - 1) >> ld); };
+    auto cell_of = [&](int y, int x, int ld) {
+        const int d = 1 << ld, Hs = (H + d - 1) >> ld, Ws = (W + d - 1) >> ld;
+        const int sub = ((y & (d - 1)) << ld) | (x & (d - 1));
+        return (sub * Hs + (y >> ld)) * Ws + (x >> ld);
+    };
+    cpc_in = cells(ld_in);
+    cpc_out = cells(ld_out);
+    cpc_res = cells(ld_res);
+    const int d = 1 << ld_in, Hs = (H + d - 1) >> ld_in, Ws = (W + d - 1) >> ld_in;
+    tab.assign((size_t)4 * cpc_in, 0);
+    for (int q = 0; q < cpc_in; ++q) {
+        const int xs = q % Ws, t = q / Ws, ys = t % Hs, sub = t / Hs;
+        const int r0 = sub >> ld_in, c0 = sub & (d - 1);
+        const int y = (ys << ld_in) + r0, x = (xs << ld_in) + c0;
+        const bool valid = y < H && x < W;
+        int mk = 0;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = ys + ky - 1, xx = xs + kx - 1;
+                // a tap is live when it stays inside the sub-map AND lands on a real image position
+                if (yy >= 0 && yy < Hs && (yy << ld_in) + r0 < H && xx >= 0 && xx < Ws && (xx << ld_in) + c0 < W) mk |= 1 << (3 * ky + kx);
+            }
+        const int bmask = (y - d >= 0 ? 1 : 0) | (y + d < H ? 2 : 0) | (x - d >= 0 ? 4 : 0) | (x + d < W ? 8 : 0);
+        tab[4 * q + 0] = mk | (bmask << 9) | ((valid ? 1 : 0) << 13);
+        tab[4 * q + 1] = valid ? cell_of(y, x, ld_out) : 0;
+        tab[4 * q + 2] = valid ? cell_of(y, x, ld_res) : 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ fp32 NCHW -> CL

@@ -59,7 +59,8 @@ enum LwMode { LW_FP32 = 0, LW_NCHW = 1, LW_TILED = 2 };
 
 struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the layer-wise plans
     ConvGeom g{};           // B/H/W/Ho/Wo filled per call for ResNet, at create for CNN
-    DevMem apk, apk16, apk16h, apk_t3h, bias, border, border_pad, w9cl;   // apk16h: fp16 fragments of the generic kernel; w9cl: conv_0 as [9 taps][C padded to 8] (conv0_cl_kernel)
+    DevMem apk, apk16, apk16h, apk_t3h, bias, border, border_pad, w9cl, postab;   // postab: conv3x3_tile position table for postab_T frames
+    int postab_T = -1, postab_cpc[3] = {0, 0, 0};   // apk16h: fp16 fragments of the generic kernel; w9cl: conv_0 as [9 taps][C padded to 8] (conv0_cl_kernel)
     float x_scale = 1.f;     // 2^S of apk16h   // apk_t3h: fp16 fragments of the tiled 3x3 kernel
     float t3h_scale = 1.f;   // 2^S of apk_t3h   // border_pad: rows padded to a multiple of 8 channels (tiled kernel)
     bool has_bias = false, has_border = false, use_x = false;   // use_x: bf16x6 kernel available for this layer
@@ -635,9 +636,37 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                 tp.Hs = (sh.H + dd - 1) / dd; tp.Ws = (sh.W + dd - 1) / dd;
                 tp.total = nb * dd * dd * tp.Hs * tp.Ws;
                 tp.rg = rg;
+                if (h->rconv[i].postab_T != T) {   // the per-cell table of this layer's geometry (once per clip length)
+                    std::vector<int> tab;
+                    build_tile_conv_table(sh.H, sh.W, ld_in, ld_out, ld_x, tab, h->rconv[i].postab_cpc[0], h->rconv[i].postab_cpc[1],
+                                          h->rconv[i].postab_cpc[2]);
+                    if ((rc = h->rconv[i].postab.upload(tab.data(), tab.size() * sizeof(int)))) return rc;
+                    h->rconv[i].postab_T = T;
+                }
+                tp.postab = h->rconv[i].postab.as<int>();
+                tp.cpc_in = h->rconv[i].postab_cpc[0]; tp.cpc_out = h->rconv[i].postab_cpc[1]; tp.cpc_res = h->rconv[i].postab_cpc[2];
                 static const int t3_dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
                 tp.debug = t3_dbg;
+                // KWS_T3_TIMING=<file> (timing builds only): phase stamps of layer KWS_T3_TIMING_LAYER (default 2) of the first chunk
+                static const char* t3_file = std::getenv("KWS_T3_TIMING");
+                static const int t3_layer = std::getenv("KWS_T3_TIMING_LAYER") ? std::atoi(std::getenv("KWS_T3_TIMING_LAYER")) : 2;
+                static DevMem t3_buf;
+                const bool t3_this = t3_file && i == t3_layer && b0 == 0 && !rg.gated;
+                if (t3_this) {
+                    std::vector<unsigned long long> z((size_t)8192 * 4 * 8, 0ull);
+                    if ((rc = t3_buf.upload(z.data(), z.size() * 8))) return rc;
+                    tp.dbg_ts = t3_buf.as<unsigned long long>();
+                }
                 HIP_TRY(launch_conv3x3_tile(tp, C, s));
+                if (t3_this) {
+                    std::vector<unsigned long long> z((size_t)8192 * 4 * 8);
+                    HIP_TRY(hipStreamSynchronize(s));
+                    HIP_TRY(hipMemcpy(z.data(), t3_buf.p, z.size() * 8, hipMemcpyDeviceToHost));
+                    if (FILE* f = std::fopen(t3_file, "wb")) {
+                        std::fwrite(z.data(), 8, z.size(), f);
+                        std::fclose(f);
+                    }
+                }
                 if (even) {
                     std::swap(xc, xn);
                     ld_x = ld_out;

@@ -289,10 +289,19 @@ struct TileConvParams {
     int f16;               // 1: two-part fp16 operands, three terms (fp32-accurate default)
     float inv_scale;       // 2^-S of the fp16 weights (1 for bf16)
     RangeGate rg;          // fp16 range guard (zero-initialised: none)
+    // Per-cell metadata of ONE clip in the input layout (build_tile_conv_table): for cell q, {tap mask | border class << 9 | valid << 13,
+    // cell of the same position in the output layout, in the residual layout, 0}; cells per clip of the three layouts.  What a lane
+    // used to decode per tile (two divisions, the sub-lattice arithmetic, nine tap tests, two layout computations: ~180 vector
+    // instructions per position) is one 16-byte load.
+    const int* postab;
+    int cpc_in, cpc_out, cpc_res;
+    unsigned long long* dbg_ts;   // KWS_T3_TIMING (with a -DT3_TIMING build): 8 stamps per workgroup for the first 8192 workgroups, or nullptr
     int debug;             // KWS_T3_DEBUG, timing experiments only (results are wrong when set): 1 skip the k-loop, 2 skip the
-                           // staging loads, 4 skip the output stores, 8 skip the residual read
+                           // staging loads, 4 skip the output stores, 8 skip the residual read, 16 skip the k-loop's weight-fragment loads
 };
 bool conv3x3_tile_supported(int C, int Cout, int Ws);
+// host side: the metadata table of one clip for a layer reading layout(2^ld_in), writing layout(2^ld_out), residual in layout(2^ld_res)
+void build_tile_conv_table(int H, int W, int ld_in, int ld_out, int ld_res, std::vector<int>& tab, int& cpc_in, int& cpc_out, int& cpc_res);
 void pack_conv3x3_tile_weights_f16(int C, const float* w /*C,C,3,3*/, float scale, std::vector<unsigned short>& dst);
 hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
 // fp32 (B, C, H, W) -> pooled (stride = window, floor; 1 x 1 = transpose only) channels-last (B, H/kh, W/kw, cp) fp32
