@@ -216,7 +216,7 @@ __device__ __forceinline__ void load_b(BFrag& b, const char* lds, int a0, int a1
             } else {                                                                  \
                 if (c.mx == 0) { MFS(0, bcur.p, accx) }                               \
                 else if (c.mx == 1) { MFS(1, bcur.p, accx) }                          \
-                else { MFS(2, bcur.p, accx) }                                         \
+                else if (c.w == 2) { MFS(2, bcur.p, accx) }   /* wave 3 owns no extra tile */ \
             }                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                        \
         }                                                                             \
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
             }
             {
                 f32x4 sx = zero;
-                if (!(p.debug & 1)) {
+                if (!(p.debug & 1) && w < 3) {   // wave 3 owns no extra tile
 #pragma unroll
                     for (int wi = 0; wi < 12; ++wi) {
                         const int oy = wi / 3, ox = wi - 3 * oy;
