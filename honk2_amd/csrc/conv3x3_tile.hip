@@ -65,6 +65,15 @@ __device__ __forceinline__ void split4(f32x4 x, u32x2 (&out)[3]) {
     }
 }
 
+// four fp32 values -> four 16-bit values (round to nearest even) of a 16-bit channels-last tensor: fp16 or bf16
+template <bool F16>
+__device__ __forceinline__ u32x2 cl_pack4(f32x4 v) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    if (F16) return (u32x2){__builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[0], v[1]}, f16x2)),
+                            __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[2], v[3]}, f16x2))};
+    return (u32x2){pack2(v[0], v[1]), pack2(v[2], v[3])};
+}
+
 // q / dv for 0 <= q < 2^24 with a precomputed reciprocal (exact after one correction step); rem receives q % dv
 __device__ __forceinline__ int fdiv(int q, int dv, float inv, int& rem) {
     int t = (int)((float)q * inv);
@@ -125,18 +134,23 @@ __device__ __forceinline__ void split4_f16(f32x4 x, u32x2 (&out)[2]) {
 // F16 (the default, fp32-accurate): operands are two-part fp16 splits, three terms per product (res8_f16x3.hip; weights
 // arrive scaled by 2^S, the accumulator is scaled back in the epilogue's FMA); the LDS cell shrinks to 2 x NB*8 x 2 B, which
 // buys 320-position tiles (5 per wave).  Otherwise bf16 parts with TERMS = 6 / 3 / 1 products (reduced-precision dtypes).
+//
+// TERMS == 1 (the `bf16` / `fp16` dtypes): the activation tensors themselves hold the 16-bit operand type, so staging is a plain
+// 16-byte copy into 96-byte LDS cells, the residual and the output move half the bytes, and three workgroups fit a CU.  The layer
+// was bound by HBM-side traffic, not by its MFMAs (profiles/r02/v9_res15_bf16_summary.json: 4.3 TB/s, matrix pipe 13 % busy).
 template <int NB, int MT, int TERMS, bool F16>
-__global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_kernel(TileConvParams p) {
-    constexpr int LP = F16 ? 2 : 3;                 // parts per LDS cell / per weight fragment group
-    constexpr int CELL = NB * 16 * LP, PART = NB * 16;
-    constexpr int GCELL = NB * 32;                  // global cell: NB*8 channels x 4 B
+__global__ __launch_bounds__(256, ((F16 && NB <= 3) || TERMS == 1) ? 3 : 2) void conv3x3_tile_kernel(TileConvParams p) {
+    constexpr bool S16 = TERMS == 1;                // 16-bit activation tensors
+    constexpr int WP = F16 ? 2 : 3;                 // parts per weight fragment group (as packed on the host)
+    constexpr int NP = t3_lds_parts(F16, TERMS);    // parts that take part in the products = parts per LDS cell
+    constexpr int CELL = NB * 16 * NP, PART = NB * 16;
+    constexpr int GCELL = S16 ? NB * 16 : NB * 32;  // global cell: NB*8 channels x 2 or 4 B
     constexpr int STEPS = (9 * NB + 3) / 4;
-    constexpr int NP = F16 ? (TERMS >= 3 ? 2 : 1) : (TERMS == 6 ? 3 : (TERMS == 3 ? 2 : 1));   // parts that take part in the products
-    constexpr int TILE_P = t3_tile_positions(F16, NB);
+    constexpr int TILE_P = t3_tile_positions(NP, NB);
     constexpr int JT = TILE_P / 64;                 // position tiles per wave (5 / 3)
-    constexpr int NQ = NB * 2;         // 4-channel quads per cell
-    constexpr int NGRP = 256 / NQ;     // cells copied per pass (21 / 42)
-    constexpr int UNR = NB == 6 ? 10 : 5;  // staging passes in flight together
+    constexpr int NQ = S16 ? NB : NB * 2;           // 16-byte chunks per global cell (8 channels of 16 bits / 4 of fp32)
+    constexpr int NGRP = 256 / NQ;     // cells copied per pass
+    constexpr int UNR = S16 ? (NB == 6 ? 10 : 4) : (NB == 6 ? 10 : 5);  // staging passes in flight together
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
 #ifdef T3_TIMING   // 100 MHz wall-clock stamps of this workgroup's phases (tools/t3_phases.py)
@@ -178,7 +192,8 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
     }
     T3_TS(8)
     // residual values of this lane's outputs: requested now, consumed in the epilogue
-    f32x4 resv[JT][MT];
+    f32x4 resv[S16 ? 1 : JT][S16 ? 1 : MT];
+    u32x2 resh[S16 ? JT : 1][S16 ? MT : 1];   // 16-bit tensors: four values in two words
     const char* const resp = reinterpret_cast<const char*>(p.res);
     if (resp && !(p.debug & 8)) {
 #pragma unroll
@@ -187,8 +202,14 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int co0 = m * 16 + 4 * g;
-                resv[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (((tmask[j] >> 13) & 1) && co0 < NB * 8) resv[j][m] = *reinterpret_cast<const f32x4*>(resp + rcell + co0 * 4);
+                const bool live = ((tmask[j] >> 13) & 1) && co0 < NB * 8;
+                if (S16) {
+                    resh[j][m] = (u32x2){0u, 0u};
+                    if (live) resh[j][m] = *reinterpret_cast<const u32x2*>(resp + rcell + co0 * 2);
+                } else {
+                    resv[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (live) resv[j][m] = *reinterpret_cast<const f32x4*>(resp + rcell + co0 * 4);
+                }
             }
         }
     }
@@ -218,7 +239,14 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
                 for (int u = 0; u < UNR; ++u) {
                     const int i = i0 + u * NGRP;
                     if (i < ncell) {
-                        if (F16) {
+                        if (S16) {           // the tensor already holds the operand type: eight channels, one 16-byte store
+                            *reinterpret_cast<f32x4*>(lds + i * CELL + qd * 16) = v[u];
+                        } else if (NP == 2 && !F16) {   // bf16x3: the two leading bf16 parts
+                            u32x2 pr[3];
+                            split4(v[u], pr);
+#pragma unroll
+                            for (int pt = 0; pt < 2; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                        } else if (F16) {
                             u32x2 pr[2];
                             split4_f16(v[u], pr);
 #pragma unroll
@@ -265,7 +293,7 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
 #define TLOADA(AR, S)                                                                                 \
     {                                                                                                 \
         _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                \
-            _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) AR[m][pt] = A[(((S) * MT + m) * LP + pt) * 64]; \
+            _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) AR[m][pt] = A[(((S) * MT + m) * WP + pt) * 64]; \
     }
     // one k-step: B fragments are fetched one position tile ahead (tile 0 of the next step during the last tile); BX / BY
     // are the two fragment buffers, BX holding tile 0 on entry; JT is odd, so BY holds the next step's tile 0 on exit
@@ -319,14 +347,31 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
             if (co0 >= NB * 8) continue;
             f32x4 v, bb = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (p.border) bb = *reinterpret_cast<const f32x4*>(p.border + bmask * (NB * 8) + co0);   // rows padded to NB*8, zeros past Cout
+            f32x4 rv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (resp) {
+                if (!S16) rv = resv[S16 ? 0 : j][S16 ? 0 : m];
+                else if (F16) {
+                    // (scalar conversions on purpose: with __builtin_bit_cast(f16x2, word) hipcc 7.2 reused word 0's halves for word 1)
+                    const u32x2 rw = resh[S16 ? j : 0][S16 ? m : 0];
+                    rv[0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[0] & 0xffffu));
+                    rv[1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[0] >> 16));
+                    rv[2] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[1] & 0xffffu));
+                    rv[3] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[1] >> 16));
+                } else {
+                    const unsigned a = resh[S16 ? j : 0][S16 ? m : 0][0], b = resh[S16 ? j : 0][S16 ? m : 0][1];
+                    rv = (f32x4){lo_f(a), hi_f(a), lo_f(b), hi_f(b)};
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float x = relu1(fmaf(acc[j][m][r], p.inv_scale, bb[r]));   // inv_scale = 2^-S of the fp16 weights (1 for bf16)
-                if (resp) x += resv[j][m][r];
+                if (resp) x += rv[r];
                 v[r] = co0 + r < p.Cout ? x : 0.f;   // padded channels hold exact zeros
                 amax = fmaxf(amax, fabsf(v[r]));
             }
-            if (!(p.debug & 4)) *reinterpret_cast<f32x4*>(outp + ocell + co0 * 4) = v;
+            if (p.debug & 4) continue;
+            if (!S16) *reinterpret_cast<f32x4*>(outp + ocell + co0 * 4) = v;
+            else *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
         }
     }
     range_note(p.rg, amax);
@@ -345,21 +390,21 @@ __global__ __launch_bounds__(256, (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_ke
 }
 
 // one tile buffer (TILE_P + 2 Ws + 2 cells + the zero cell)
-size_t conv3x3_tile_lds_bytes(int cp, int Ws, bool f16) {
-    return (size_t)(t3_tile_positions(f16, cp / 8) + 2 * Ws + 3) * cp * (f16 ? 4 : 6) + 512;   // + the k-step table
+size_t conv3x3_tile_lds_bytes(int cp, int Ws, int parts) {
+    return (size_t)(t3_tile_positions(parts, cp / 8) + 2 * Ws + 3) * cp * 2 * parts + 512;   // + the k-step table
 }
 
 bool conv3x3_tile_supported(int C, int Cout, int Ws) {
     const int cp = (C + 7) / 8 * 8;
-    return C == Cout && (cp == 24 || cp == 48) && conv3x3_tile_lds_bytes(cp, Ws, false) <= 160 * 1024 - 512 &&
-           conv3x3_tile_lds_bytes(cp, Ws, true) <= 160 * 1024 - 512;
+    return C == Cout && (cp == 24 || cp == 48) && conv3x3_tile_lds_bytes(cp, Ws, 3) <= 160 * 1024 - 512 &&
+           conv3x3_tile_lds_bytes(cp, Ws, 2) <= 160 * 1024 - 512;
 }
 
 template <int NB, int MT, int TERMS, bool F16>
 static hipError_t launch_t3k(const TileConvParams& p, hipStream_t s) {
-    constexpr int tile = t3_tile_positions(F16, NB);
+    constexpr int tile = t3_tile_positions(t3_lds_parts(F16, TERMS), NB);
     const unsigned grid = (unsigned)((p.total + tile - 1) / tile);
-    const size_t lds = conv3x3_tile_lds_bytes(NB * 8, p.Ws, F16);
+    const size_t lds = conv3x3_tile_lds_bytes(NB * 8, p.Ws, t3_lds_parts(F16, TERMS));
     auto k = conv3x3_tile_kernel<NB, MT, TERMS, F16>;
     static DeviceOnce attr_once;   // per instantiation: allow > 64 KB of dynamic LDS
     if (attr_once.first()) {
@@ -500,8 +545,10 @@ hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, i
 // position x four channels, plain fp32 FMAs over the 3 x 3 taps of every window member (1.6 MFLOP per clip: the pass is bound by
 // its 0.8 MB per clip of output, not by arithmetic).  Replaces conv_igemm_kernel (NCHW out, 0.41 ms per 1 024 res15 clips at 1.6
 // TB/s) + nchw_to_cl_kernel (0.29 - 0.56 ms).  Lanes run quad-fastest, so the 12 lanes of a position read the same input words.
+// CLT: element type of the output tensor (CL_F32, or the 16-bit operand type of the `bf16` / `fp16` dtypes).
+template <int CLT>
 __global__ __launch_bounds__(256) void conv0_cl_kernel(const float* __restrict__ feat, const float* __restrict__ w9 /*[9][cp]*/,
-                                                       float* __restrict__ out, long long total, int T, int F, int Hp, int Wp,
+                                                       void* __restrict__ out, long long total, int T, int F, int Hp, int Wp,
                                                        int kh, int kw, int cp, RangeGate rg) {
     if (range_gate_closed(rg)) return;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -538,27 +585,30 @@ __global__ __launch_bounds__(256) void conv0_cl_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum[r] = sum[r] / (float)(kh * kw);   // a true division, as nn.AvgPool2d's sum / count
     }
-    *reinterpret_cast<f32x4*>(out + ((b * Hp + oy) * (long long)Wp + ox) * cp + 4 * q) = sum;
+    const long long o = ((b * Hp + oy) * (long long)Wp + ox) * cp + 4 * q;
+    if (CLT == CL_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + o) = sum;
+    else *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(out) + o) = cl_pack4<CLT == CL_F16>(sum);
     float amax = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(sum[r]));
     range_note(rg, amax);
 }
 
-hipError_t launch_conv0_cl(const float* feat, const float* w9, float* out, int B, int T, int F, int kh, int kw, int cp,
+hipError_t launch_conv0_cl(const float* feat, const float* w9, void* out, int cl_type, int B, int T, int F, int kh, int kw, int cp,
                            hipStream_t s, RangeGate rg) {
     const int Hp = T / kh, Wp = F / kw;
     const long long total = (long long)B * Hp * Wp * (cp / 4);
     if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(conv0_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, w9, out, total, T, F, Hp, Wp,
-                       kh, kw, cp, rg);
+    auto k = cl_type == CL_BF16 ? conv0_cl_kernel<CL_BF16> : cl_type == CL_F16 ? conv0_cl_kernel<CL_F16> : conv0_cl_kernel<CL_F32>;
+    hipLaunchKernelGGL(k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, w9, out, total, T, F, Hp, Wp, kh, kw, cp, rg);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ mean + linear on CL
 // ResNet tail (reference model/resnet.py:57-59), last BatchNorm folded in: mean(BN(x)) == BN(mean(x)).
-// One workgroup per clip; x is (B, HW, cp) fp32 in layout(1).
-__global__ __launch_bounds__(256) void mean_linear_cl_kernel(const float* __restrict__ x, float* __restrict__ logits,
+// One workgroup per clip; x is (B, HW, cp) in layout(1), element type CLT.
+template <int CLT>
+__global__ __launch_bounds__(256) void mean_linear_cl_kernel(const void* __restrict__ x, float* __restrict__ logits,
                                                              int C, int cp, int HW, const float* mean, const float* rstd,
                                                              const float* __restrict__ wt, const float* __restrict__ bias,
                                                              int n_out, RangeGate rg) {
@@ -567,10 +617,16 @@ __global__ __launch_bounds__(256) void mean_linear_cl_kernel(const float* __rest
     const int b = blockIdx.x;
     const int nsl = 256 / cp > 0 ? 256 / cp : 1;   // cell slices summed in parallel
     const int c = threadIdx.x % cp, sl = threadIdx.x / cp;
-    const float* base = x + (size_t)b * HW * cp;
+    auto at = [&](size_t i) -> float {
+        if (CLT == CL_F32) return reinterpret_cast<const float*>(x)[i];
+        const unsigned short u = reinterpret_cast<const unsigned short*>(x)[i];
+        if (CLT == CL_F16) return (float)__builtin_bit_cast(_Float16, u);
+        return __builtin_bit_cast(float, (unsigned)u << 16);
+    };
+    const size_t base = (size_t)b * HW * cp;
     if (sl < nsl) {
         float s = 0.f;
-        for (int i = sl; i < HW; i += nsl) s += base[(size_t)i * cp + c];
+        for (int i = sl; i < HW; i += nsl) s += at(base + (size_t)i * cp + c);
         sm[sl * cp + c] = s;
     }
     __syncthreads();
@@ -590,12 +646,13 @@ __global__ __launch_bounds__(256) void mean_linear_cl_kernel(const float* __rest
     }
 }
 
-hipError_t launch_mean_linear_cl(const float* x, float* logits, int B, int C, int cp, int HW, const float* mean,
+hipError_t launch_mean_linear_cl(const void* x, int cl_type, float* logits, int B, int C, int cp, int HW, const float* mean,
                                  const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s, RangeGate rg) {
     if (B <= 0) return hipSuccess;
     if (cp > 256) return hipErrorInvalidValue;
     const int nsl = 256 / cp;
-    hipLaunchKernelGGL(mean_linear_cl_kernel, dim3((unsigned)B), dim3(256), (size_t)(nsl + 1) * cp * sizeof(float), s, x,
+    auto k = cl_type == CL_BF16 ? mean_linear_cl_kernel<CL_BF16> : cl_type == CL_F16 ? mean_linear_cl_kernel<CL_F16> : mean_linear_cl_kernel<CL_F32>;
+    hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(256), (size_t)(nsl + 1) * cp * sizeof(float), s, x,
                        logits, C, cp, HW, mean, rstd, w, bias, n_out, rg);
     return hipGetLastError();
 }

@@ -612,8 +612,12 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
         auto pass = [&](int terms, RangeGate rg) -> int {
-            // conv_0 + ReLU (+ AvgPool) in plain fp32, straight into the channels-last tensor
-            HIP_TRY(launch_conv0_cl(feat + (size_t)b0 * sh.T * sh.F, h->rconv[0].w9cl.as<float>(), X, nb, sh.T, sh.F,
+            // conv_0 + ReLU (+ AvgPool) in plain fp32, straight into the channels-last tensor; with single-term products (the
+            // `bf16` / `fp16` dtypes) the tensors between the layers hold the 16-bit operand type itself
+            int m_f16, m_terms;
+            decode_mode(terms, m_f16, m_terms);
+            const int clt = m_terms == 1 ? (m_f16 ? CL_F16 : CL_BF16) : CL_F32;
+            HIP_TRY(launch_conv0_cl(feat + (size_t)b0 * sh.T * sh.F, h->rconv[0].w9cl.as<float>(), X, clt, nb, sh.T, sh.F,
                                     sh.pooled ? d.pool_h : 1, sh.pooled ? d.pool_w : 1, cp, s, rg));
             float* xc = X;
             float* xn = X2;
@@ -673,7 +677,7 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                 }
             }
             const float* fin = (d.n_layers % 2 == 0) ? xc : Y;
-            HIP_TRY(launch_mean_linear_cl(fin, logits + (size_t)b0 * d.n_labels, nb, C, cp, sh.H * sh.W,
+            HIP_TRY(launch_mean_linear_cl(fin, clt, logits + (size_t)b0 * d.n_labels, nb, C, cp, sh.H * sh.W,
                                           h->bn_mean.as<float>() + (size_t)(d.n_layers - 1) * C,
                                           h->bn_rstd.as<float>() + (size_t)(d.n_layers - 1) * C, h->out_w.as<float>(),
                                           h->out_b.as<float>(), d.n_labels, s, rg));

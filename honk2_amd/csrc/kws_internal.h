@@ -271,14 +271,18 @@ void pack_conv_weights_bf16x6(const ConvGeom& g, const float* w, std::vector<uns
 void pack_conv_weights_f16x3(const ConvGeom& g, const float* w, float scale, std::vector<unsigned short>& dst);
 // LDS-tiled 3x3 "same" conv with power-of-two dilation over channels-last fp32 tensors in sub-map layouts
 // (conv3x3_tile.hip)
-constexpr int T3_TILE_P = 192;         // bf16 parts (reduced-precision dtypes): 3 position tiles per wave
-constexpr int T3_TILE_P_F16 = 320;     // fp16 parts (default), 41-48 channels: 5 position tiles per wave, two workgroups per CU
-constexpr int T3_TILE_P_F16_NARROW = 192;   // fp16 parts, 17-24 channels: 3 tiles per wave, three workgroups per CU (+14 % measured)
-constexpr int t3_tile_positions(bool f16, int nb) { return f16 ? (nb <= 3 ? T3_TILE_P_F16_NARROW : T3_TILE_P_F16) : T3_TILE_P; }
+constexpr int T3_TILE_P = 192;         // three bf16 parts per LDS cell (KWS_MATRIX_PARTS=bf16): 3 position tiles per wave
+constexpr int T3_TILE_P_F16 = 320;     // two parts or one (fp16 default, bf16x3, the 16-bit dtypes), 41-48 channels: 5 position tiles per wave
+constexpr int T3_TILE_P_F16_NARROW = 192;   // the same, 17-24 channels: 3 tiles per wave, three workgroups per CU (+14 % measured)
+// parts of an operand that the LDS cell holds = parts that take part in the products (terms: 6 / 3 / 1 products per fp32 product)
+constexpr int t3_lds_parts(bool f16, int terms) { return f16 ? (terms >= 3 ? 2 : 1) : (terms == 6 ? 3 : (terms == 3 ? 2 : 1)); }
+constexpr int t3_tile_positions(int parts, int nb) { return parts >= 3 ? T3_TILE_P : (nb <= 3 ? T3_TILE_P_F16_NARROW : T3_TILE_P_F16); }
 struct TileConvParams {
-    const float* in;       // CL tensor in layout(2^ld_in): [clip][y mod d][x mod d][ceil(H/d)][ceil(W/d)][cp] fp32
-    float* out;            // CL tensor, written in layout(2^ld_out)
-    const float* res;      // residual CL tensor in layout(2^ld_res), or nullptr
+    // Activations are fp32, except with single-term products (terms == 1: the `bf16` / `fp16` dtypes), where the three tensors hold
+    // 16-bit values of the operand type (bf16, or fp16 when f16 is set): staging is then a plain copy and HBM traffic halves.
+    const void* in;        // CL tensor in layout(2^ld_in): [clip][y mod d][x mod d][ceil(H/d)][ceil(W/d)][cp]
+    void* out;             // CL tensor, written in layout(2^ld_out)
+    const void* res;       // residual CL tensor in layout(2^ld_res), or nullptr
     const unsigned short* apk16;   // f16: pack_conv3x3_tile_weights_f16; else pack_conv_weights_bf16x6 with MT = all tiles
     const float* border;   // (16, C padded to 8) border-bias table, zeros in the padding, or nullptr
     int B, H, W, Cout;
@@ -307,10 +311,12 @@ hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
 // fp32 (B, C, H, W) -> pooled (stride = window, floor; 1 x 1 = transpose only) channels-last (B, H/kh, W/kw, cp) fp32
 hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, int W, int kh, int kw, int is_max, int cp,
                              hipStream_t s, RangeGate rg = RangeGate{nullptr, 0});
-// conv_0 (3x3, pad 1) + ReLU [+ AvgPool(kh, kw)] of a ResNet straight into the channels-last fp32 tensor; w9 = weights as [9 taps][cp]
-hipError_t launch_conv0_cl(const float* feat, const float* w9, float* out, int B, int T, int F, int kh, int kw, int cp,
+// element type of a channels-last activation tensor of the tiled plan
+enum ClType { CL_F32 = 0, CL_BF16 = 1, CL_F16 = 2 };
+// conv_0 (3x3, pad 1) + ReLU [+ AvgPool(kh, kw)] of a ResNet straight into the channels-last tensor; w9 = weights as [9 taps][cp]
+hipError_t launch_conv0_cl(const float* feat, const float* w9, void* out, int cl_type, int B, int T, int F, int kh, int kw, int cp,
                            hipStream_t s, RangeGate rg = RangeGate{nullptr, 0});
-hipError_t launch_mean_linear_cl(const float* x, float* logits, int B, int C, int cp, int HW, const float* mean,
+hipError_t launch_mean_linear_cl(const void* x, int cl_type, float* logits, int B, int C, int cp, int HW, const float* mean,
                                  const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s,
                                  RangeGate rg = RangeGate{nullptr, 0});
 // out[i] = (relu?)(bias[co] + sum_z partial[z][i]) for i over (B, Cout, npc)
