@@ -169,51 +169,36 @@ __global__ __launch_bounds__(256, ((F16 && NB <= 3) || TERMS == 1) ? 3 : 2) void
     const int ld = p.ld_in, d = 1 << ld, dmask = d - 1;
     const int Hs = p.Hs, Ws = p.Ws;
     T3_TS(9)
-    const int P0 = (int)blockIdx.x * TILE_P;
+    // Consecutive tiles share their halo cells: blocks that share an XCD (blockIdx mod 8) take one contiguous run of tiles, so a
+    // halo re-read hits that XCD's L2 instead of going out to the fabric again (bijective for any grid size).
+    int tile_id = (int)blockIdx.x;
+    if (!(p.debug & 32)) {
+        const int nwg = (int)gridDim.x, xcd = tile_id & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile_id >> 3);
+    }
+    const int P0 = tile_id * TILE_P;
     const int ncell = TILE_P + 2 * Ws + 2;
     const int zero_off = ncell * CELL;
+    const int border_off = zero_off + CELL + 512;   // after the zero cell and the k-step table
     const float inv_ws = 1.0f / (float)Ws, inv_hs = 1.0f / (float)Hs;
 
     // ---------------------------------------------------------------- this lane's output positions: one table entry each
+    // (requested first, consumed after the staging loads have been issued: one round trip instead of two in a row)
     int lbase[JT], tmask[JT], ocl[JT], rcl[JT];   // tmask: tap mask | border class << 9 | valid << 13; ocl / rcl: output / residual cell
     const float inv_cpc = 1.0f / (float)p.cpc_in;
     (void)inv_ws; (void)inv_hs; (void)dmask; (void)Hs;
+    i32x4 pe[JT];
+    int pb[JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         const int local = (w * JT + j) * 16 + pcol;
         const int P = min(P0 + local, p.total - 1);
         int q;
-        const int b = fdiv(P, p.cpc_in, inv_cpc, q);
-        const i32x4 e = *reinterpret_cast<const i32x4*>(p.postab + 4 * q);
-        tmask[j] = P0 + local < p.total ? e[0] : 0;
-        ocl[j] = b * p.cpc_out + e[1];
-        rcl[j] = b * p.cpc_res + e[2];
+        pb[j] = fdiv(P, p.cpc_in, inv_cpc, q);
+        pe[j] = *reinterpret_cast<const i32x4*>(p.postab + 4 * q);
         lbase[j] = (local + Ws + 1) * CELL;
     }
     T3_TS(8)
-    // residual values of this lane's outputs: requested now, consumed in the epilogue
-    f32x4 resv[S16 ? 1 : JT][S16 ? 1 : MT];
-    u32x2 resh[S16 ? JT : 1][S16 ? MT : 1];   // 16-bit tensors: four values in two words
-    const char* const resp = reinterpret_cast<const char*>(p.res);
-    if (resp && !(p.debug & 8)) {
-#pragma unroll
-        for (int j = 0; j < JT; ++j) {
-            const size_t rcell = (size_t)rcl[j] * GCELL;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int co0 = m * 16 + 4 * g;
-                const bool live = ((tmask[j] >> 13) & 1) && co0 < NB * 8;
-                if (S16) {
-                    resh[j][m] = (u32x2){0u, 0u};
-                    if (live) resh[j][m] = *reinterpret_cast<const u32x2*>(resp + rcell + co0 * 2);
-                } else {
-                    resv[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (live) resv[j][m] = *reinterpret_cast<const f32x4*>(resp + rcell + co0 * 4);
-                }
-            }
-        }
-    }
-
     T3_TS(1)
     // ---------------------------------------------------------------- stage cells [P0 - Ws - 1, P0 + TILE_P + Ws + 1)
     {
@@ -223,6 +208,13 @@ __global__ __launch_bounds__(256, ((F16 && NB <= 3) || TERMS == 1) ? 3 : 2) void
             const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
             // (zero-weight padding blocks, tap >= 9, test bit 31 of the mask word, which is never set: they read the zero cell)
             reinterpret_cast<int2_*>(lds + zero_off + CELL)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16 - zero_off, tap < 9 ? tap : 31};
+        }
+        // the border-bias table (16 border classes x NB*8 channels) goes to LDS: read from global memory in the epilogue, every one of
+        // its loads waited -- vmcnt counts loads and stores alike -- for the previous block's output store as well (6.5 of 18 us per tile)
+        if (tid < 32 * NB) {
+            f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.border) bv = *reinterpret_cast<const f32x4*>(p.border + 4 * tid);
+            *reinterpret_cast<f32x4*>(lds + border_off + 16 * tid) = bv;
         }
         if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
@@ -262,6 +254,37 @@ __global__ __launch_bounds__(256, ((F16 && NB <= 3) || TERMS == 1) ? 3 : 2) void
             }
         }
     }
+    // the table entries have arrived with the staging loads; residual values of this lane's outputs: requested now, consumed in
+    // the epilogue
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int local = (w * JT + j) * 16 + pcol;
+        tmask[j] = P0 + local < p.total ? pe[j][0] : 0;
+        ocl[j] = pb[j] * p.cpc_out + pe[j][1];
+        rcl[j] = pb[j] * p.cpc_res + pe[j][2];
+    }
+    f32x4 resv[S16 ? 1 : JT][S16 ? 1 : MT];
+    u32x2 resh[S16 ? JT : 1][S16 ? MT : 1];   // 16-bit tensors: four values in two words
+    const char* const resp = reinterpret_cast<const char*>(p.res);
+    if (resp && !(p.debug & 8)) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const size_t rcell = (size_t)rcl[j] * GCELL;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = m * 16 + 4 * g;
+                const bool live = ((tmask[j] >> 13) & 1) && co0 < NB * 8;
+                if (S16) {
+                    resh[j][m] = (u32x2){0u, 0u};
+                    if (live) resh[j][m] = *reinterpret_cast<const u32x2*>(resp + rcell + co0 * 2);
+                } else {
+                    resv[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (live) resv[j][m] = *reinterpret_cast<const f32x4*>(resp + rcell + co0 * 4);
+                }
+            }
+        }
+    }
+
     T3_TS(2)
     __syncthreads();
     T3_TS(3)
@@ -346,7 +369,7 @@ __global__ __launch_bounds__(256, ((F16 && NB <= 3) || TERMS == 1) ? 3 : 2) void
             const int co0 = m * 16 + 4 * g;
             if (co0 >= NB * 8) continue;
             f32x4 v, bb = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (p.border) bb = *reinterpret_cast<const f32x4*>(p.border + bmask * (NB * 8) + co0);   // rows padded to NB*8, zeros past Cout
+            bb = *reinterpret_cast<const f32x4*>(lds + border_off + (bmask * (NB * 8) + co0) * 4);   // rows padded to NB*8, zeros past Cout
             f32x4 rv = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (resp) {
                 if (!S16) rv = resv[S16 ? 0 : j][S16 ? 0 : m];
@@ -391,7 +414,7 @@ __global__ __launch_bounds__(256, ((F16 && NB <= 3) || TERMS == 1) ? 3 : 2) void
 
 // one tile buffer (TILE_P + 2 Ws + 2 cells + the zero cell)
 size_t conv3x3_tile_lds_bytes(int cp, int Ws, int parts) {
-    return (size_t)(t3_tile_positions(parts, cp / 8) + 2 * Ws + 3) * cp * 2 * parts + 512;   // + the k-step table
+    return (size_t)(t3_tile_positions(parts, cp / 8) + 2 * Ws + 3) * cp * 2 * parts + 512 + 16 * cp * 4;   // + the k-step and border tables
 }
 
 bool conv3x3_tile_supported(int C, int Cout, int Ws) {
