@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, ((F16 && NB <= 3) || TERMS == 1) ? 3 : 2) void
             if (resp) {
                 if (!S16) rv = resv[S16 ? 0 : j][S16 ? 0 : m];
                 else if (F16) {
-                    // (scalar conversions on purpose: with __builtin_bit_cast(f16x2, word) hipcc 7.2 reused word 0's halves for word 1)
+                    // (scalar conversions on purpose: __builtin_bit_cast of a vector ELEMENT reads element 0 with hipcc 7.2)
                     const u32x2 rw = resh[S16 ? j : 0][S16 ? m : 0];
                     rv[0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[0] & 0xffffu));
                     rv[1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[0] >> 16));
@@ -568,68 +568,99 @@ hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, i
 // position x four channels, plain fp32 FMAs over the 3 x 3 taps of every window member (1.6 MFLOP per clip: the pass is bound by
 // its 0.8 MB per clip of output, not by arithmetic).  Replaces conv_igemm_kernel (NCHW out, 0.41 ms per 1 024 res15 clips at 1.6
 // TB/s) + nchw_to_cl_kernel (0.29 - 0.56 ms).  Lanes run quad-fastest, so the 12 lanes of a position read the same input words.
-// CLT: element type of the output tensor (CL_F32, or the 16-bit operand type of the `bf16` / `fp16` dtypes).
-template <int CLT>
+// CLT: element type of the output tensor (CL_F32, or the 16-bit operand type of the `bf16` / `fp16` dtypes).  A thread owns one 16-byte
+// chunk of the output cell (4 fp32 / 8 16-bit channels) of C0_PX consecutive output positions, its 9 x (4 | 8) weights in registers:
+// with one position per thread the nine 16-byte weight loads of every thread kept the CU's vector-memory path busy for 144 of 180
+// clocks per wave (0.28 ms per 1 024 res15 clips, three times what the output write needs).
+// (Pooled outputs already cost kh*kw positions each: one per thread.)
+template <int CLT, int C0_PX>
 __global__ __launch_bounds__(256) void conv0_cl_kernel(const float* __restrict__ feat, const float* __restrict__ w9 /*[9][cp]*/,
-                                                       void* __restrict__ out, long long total, int T, int F, int Hp, int Wp,
-                                                       int kh, int kw, int cp, RangeGate rg) {
+                                                       void* __restrict__ out, long long total /* threads */, long long npos, int T, int F,
+                                                       int Hp, int Wp, int kh, int kw, int cp, RangeGate rg) {
     if (range_gate_closed(rg)) return;
+    constexpr int EPT = CLT == CL_F32 ? 4 : 8;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int nq = cp / 4;
+    const int nq = cp / EPT;
     const int q = (int)(i % nq);
-    long long t = i / nq;
-    const int ox = (int)(t % Wp);
-    t /= Wp;
-    const int oy = (int)(t % Hp);
-    const long long b = t / Hp;
-    f32x4 w[9];
+    const long long pos0 = (i / nq) * C0_PX;
+    float w[9][EPT];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f32x4*>(w9 + k * cp + 4 * q);
-    const float* src = feat + b * (long long)T * F;
-    f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int my = 0; my < kh; ++my)
-        for (int mx = 0; mx < kw; ++mx) {
-            const int y = oy * kh + my, x = ox * kw + mx;
-            f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 9; ++k)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int yy = y + ky - 1, xx = x + kx - 1;
-                    const float v = (yy >= 0 && yy < T && xx >= 0 && xx < F) ? src[yy * F + xx] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) c[r] = fmaf(w[3 * ky + kx][r], v, c[r]);
-                }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sum[r] += fmaxf(c[r], 0.f);
+        for (int e = 0; e < EPT; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(w9 + k * cp + EPT * q + e);
+            w[k][e] = t[0]; w[k][e + 1] = t[1]; w[k][e + 2] = t[2]; w[k][e + 3] = t[3];
         }
-    if (kh * kw > 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sum[r] = sum[r] / (float)(kh * kw);   // a true division, as nn.AvgPool2d's sum / count
-    }
-    const long long o = ((b * Hp + oy) * (long long)Wp + ox) * cp + 4 * q;
-    if (CLT == CL_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + o) = sum;
-    else *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(out) + o) = cl_pack4<CLT == CL_F16>(sum);
+    int ox = (int)(pos0 % Wp);
+    long long t = pos0 / Wp;
+    int oy = (int)(t % Hp);
+    long long b = t / Hp;
     float amax = 0.f;
+    for (int u = 0; u < C0_PX && pos0 + u < npos; ++u) {
+        const float* src = feat + b * (long long)T * F;
+        float sum[EPT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(sum[r]));
+        for (int e = 0; e < EPT; ++e) sum[e] = 0.f;
+        for (int my = 0; my < kh; ++my)
+            for (int mx = 0; mx < kw; ++mx) {
+                const int y = oy * kh + my, x = ox * kw + mx;
+                float c[EPT];
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) c[e] = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int yy = y + ky - 1, xx = x + kx - 1;
+                        const float v = (yy >= 0 && yy < T && xx >= 0 && xx < F) ? src[yy * F + xx] : 0.f;
+#pragma unroll
+                        for (int e = 0; e < EPT; ++e) c[e] = fmaf(w[3 * ky + kx][e], v, c[e]);
+                    }
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) sum[e] += fmaxf(c[e], 0.f);
+            }
+        if (kh * kw > 1) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) sum[e] = sum[e] / (float)(kh * kw);   // a true division, as nn.AvgPool2d's sum / count
+        }
+        const long long o = (pos0 + u) * cp + EPT * q;
+        if (CLT == CL_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + o) = (f32x4){sum[0], sum[1], sum[2], sum[3]};
+        else {
+            const u32x2 lo = cl_pack4<CLT == CL_F16>((f32x4){sum[0], sum[1], sum[2], sum[3]});
+            const u32x2 hi = cl_pack4<CLT == CL_F16>((f32x4){sum[EPT - 4], sum[EPT - 3], sum[EPT - 2], sum[EPT - 1]});
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(out) + o) = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) amax = fmaxf(amax, fabsf(sum[e]));
+        if (++ox == Wp) {
+            ox = 0;
+            if (++oy == Hp) {
+                oy = 0;
+                ++b;
+            }
+        }
+    }
     range_note(rg, amax);
 }
 
 hipError_t launch_conv0_cl(const float* feat, const float* w9, void* out, int cl_type, int B, int T, int F, int kh, int kw, int cp,
                            hipStream_t s, RangeGate rg) {
     const int Hp = T / kh, Wp = F / kw;
-    const long long total = (long long)B * Hp * Wp * (cp / 4);
+    const long long npos = (long long)B * Hp * Wp;
+    const int px = kh * kw > 1 ? 1 : 4;
+    const long long total = (npos + px - 1) / px * (cp / (cl_type == CL_F32 ? 4 : 8));
     if (total <= 0) return hipSuccess;
-    auto k = cl_type == CL_BF16 ? conv0_cl_kernel<CL_BF16> : cl_type == CL_F16 ? conv0_cl_kernel<CL_F16> : conv0_cl_kernel<CL_F32>;
-    hipLaunchKernelGGL(k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, w9, out, total, T, F, Hp, Wp, kh, kw, cp, rg);
+    auto k = px == 1 ? (cl_type == CL_BF16 ? conv0_cl_kernel<CL_BF16, 1> : cl_type == CL_F16 ? conv0_cl_kernel<CL_F16, 1> : conv0_cl_kernel<CL_F32, 1>)
+                     : (cl_type == CL_BF16 ? conv0_cl_kernel<CL_BF16, 4> : cl_type == CL_F16 ? conv0_cl_kernel<CL_F16, 4> : conv0_cl_kernel<CL_F32, 4>);
+    hipLaunchKernelGGL(k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, w9, out, total, npos, T, F, Hp, Wp, kh, kw, cp, rg);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ mean + linear on CL
 // ResNet tail (reference model/resnet.py:57-59), last BatchNorm folded in: mean(BN(x)) == BN(mean(x)).
-// One workgroup per clip; x is (B, HW, cp) in layout(1), element type CLT.
+// One workgroup per clip; x is (B, HW, cp) in layout(1), element type CLT.  A thread owns one 16-byte chunk of the cell (4 fp32 or 8
+// 16-bit channels) and every nsl-th cell, four loads in flight (element-wise 2- / 4-byte reads ran at 1.2 TB/s).
 template <int CLT>
 __global__ __launch_bounds__(256) void mean_linear_cl_kernel(const void* __restrict__ x, float* __restrict__ logits,
                                                              int C, int cp, int HW, const float* mean, const float* rstd,
@@ -637,20 +668,50 @@ __global__ __launch_bounds__(256) void mean_linear_cl_kernel(const void* __restr
                                                              int n_out, RangeGate rg) {
     extern __shared__ float sm[];   // [nsl][cp] partial sums, then [cp] means
     if (range_gate_closed(rg)) return;
+    constexpr int EPC = CLT == CL_F32 ? 4 : 8;   // elements per 16-byte chunk
     const int b = blockIdx.x;
-    const int nsl = 256 / cp > 0 ? 256 / cp : 1;   // cell slices summed in parallel
-    const int c = threadIdx.x % cp, sl = threadIdx.x / cp;
-    auto at = [&](size_t i) -> float {
-        if (CLT == CL_F32) return reinterpret_cast<const float*>(x)[i];
-        const unsigned short u = reinterpret_cast<const unsigned short*>(x)[i];
-        if (CLT == CL_F16) return (float)__builtin_bit_cast(_Float16, u);
-        return __builtin_bit_cast(float, (unsigned)u << 16);
-    };
-    const size_t base = (size_t)b * HW * cp;
+    const int nq = cp / EPC, nsl = 256 / nq;     // chunks per cell, cell slices summed in parallel
+    const int qd = threadIdx.x % nq, sl = threadIdx.x / nq;
+    const char* base = reinterpret_cast<const char*>(x) + ((size_t)b * HW * cp + (size_t)qd * EPC) * (CLT == CL_F32 ? 4 : 2);
+    const size_t cell_b = (size_t)cp * (CLT == CL_F32 ? 4 : 2);
     if (sl < nsl) {
-        float s = 0.f;
-        for (int i = sl; i < HW; i += nsl) s += at(base + (size_t)i * cp + c);
-        sm[sl * cp + c] = s;
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        auto add = [&](u32x4 v) {
+            if constexpr (CLT == CL_F32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned word = v[e];   // (never __builtin_bit_cast a vector ELEMENT: hipcc 7.2 then reads element 0)
+                    acc[e] += __builtin_bit_cast(float, word);
+                }
+            } else if constexpr (CLT == CL_F16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned word = v[e];
+                    acc[2 * e] += (float)__builtin_bit_cast(_Float16, (unsigned short)(word & 0xffffu));
+                    acc[2 * e + 1] += (float)__builtin_bit_cast(_Float16, (unsigned short)(word >> 16));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned word = v[e];
+                    acc[2 * e] += lo_f(word);
+                    acc[2 * e + 1] += hi_f(word);
+                }
+            }
+        };
+        int i = sl;
+        for (; i + 3 * nsl < HW; i += 4 * nsl) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(base + (size_t)(i + u * nsl) * cell_b);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(v[u]);
+        }
+        for (; i < HW; i += nsl) add(*reinterpret_cast<const u32x4*>(base + (size_t)i * cell_b));
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) sm[sl * cp + qd * EPC + e] = acc[e];
     }
     __syncthreads();
     float* mv = sm + nsl * cp;
@@ -672,8 +733,8 @@ __global__ __launch_bounds__(256) void mean_linear_cl_kernel(const void* __restr
 hipError_t launch_mean_linear_cl(const void* x, int cl_type, float* logits, int B, int C, int cp, int HW, const float* mean,
                                  const float* rstd, const float* w, const float* bias, int n_out, hipStream_t s, RangeGate rg) {
     if (B <= 0) return hipSuccess;
-    if (cp > 256) return hipErrorInvalidValue;
-    const int nsl = 256 / cp;
+    if (cp > 256 || cp % 8) return hipErrorInvalidValue;
+    const int nsl = 256 / (cp / (cl_type == CL_F32 ? 4 : 8));
     auto k = cl_type == CL_BF16 ? mean_linear_cl_kernel<CL_BF16> : cl_type == CL_F16 ? mean_linear_cl_kernel<CL_F16> : mean_linear_cl_kernel<CL_F32>;
     hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(256), (size_t)(nsl + 1) * cp * sizeof(float), s, x,
                        logits, C, cp, HW, mean, rstd, w, bias, n_out, rg);
