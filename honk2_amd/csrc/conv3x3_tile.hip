@@ -139,7 +139,7 @@ __device__ __forceinline__ void split4_f16(f32x4 x, u32x2 (&out)[2]) {
 // 16-byte copy into 96-byte LDS cells, the residual and the output move half the bytes, and three workgroups fit a CU.  The layer
 // was bound by HBM-side traffic, not by its MFMAs (profiles/r02/v9_res15_bf16_summary.json: 4.3 TB/s, matrix pipe 13 % busy).
 template <int NB, int MT, int TERMS, bool F16>
-__global__ __launch_bounds__(256, ((F16 && NB <= 3) || TERMS == 1) ? 3 : 2) void conv3x3_tile_kernel(TileConvParams p) {
+__global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3 : 2) void conv3x3_tile_kernel(TileConvParams p) {
     constexpr bool S16 = TERMS == 1;                // 16-bit activation tensors
     constexpr int WP = F16 ? 2 : 3;                 // parts per weight fragment group (as packed on the host)
     constexpr int NP = t3_lds_parts(F16, TERMS);    // parts that take part in the products = parts per LDS cell
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, ((F16 && NB <= 3) || TERMS == 1) ? 3 : 2) void
     constexpr int JT = TILE_P / 64;                 // position tiles per wave (5 / 3)
     constexpr int NQ = S16 ? NB : NB * 2;           // 16-byte chunks per global cell (8 channels of 16 bits / 4 of fp32)
     constexpr int NGRP = 256 / NQ;     // cells copied per pass
-    constexpr int UNR = S16 ? (NB == 6 ? 10 : 4) : (NB == 6 ? 10 : 5);  // staging passes in flight together
+    constexpr int UNR = S16 ? (NB == 6 ? (TILE_P <= 192 ? 7 : (TILE_P <= 320 ? 10 : 13)) : 4) : (NB == 6 ? 10 : 5);  // staging passes in flight together
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
 #ifdef T3_TIMING   // 100 MHz wall-clock stamps of this workgroup's phases (tools/t3_phases.py)

@@ -64,6 +64,8 @@ struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the l
     float x_scale = 1.f;     // 2^S of apk16h   // apk_t3h: fp16 fragments of the tiled 3x3 kernel
     float t3h_scale = 1.f;   // 2^S of apk_t3h   // border_pad: rows padded to a multiple of 8 channels (tiled kernel)
     bool has_bias = false, has_border = false, use_x = false;   // use_x: bf16x6 kernel available for this layer
+    DevMem apk_band;         // conv_band.hip fragments of a cnn-* conv_1 (fp16 parts x band_scale)
+    float band_scale = 1.f;
     std::vector<float> w_host;   // ResNet: raw weights kept until finalize() folds the previous BatchNorm in
 };
 
@@ -111,6 +113,11 @@ struct kws_handle {
     std::vector<std::string> clin_names;
     int cnn_shape[3][3] = {};              // (C,H,W) after conv/pool stage i (index 0 = input)
     size_t cnn_max_elems = 0;              // largest per-clip activation
+    // "cnn_band" plan (fp16-part modes): conv_0 writes channels-last cells, conv_1 runs in conv_band.hip, the first Linear reads
+    // its channels-last output through column-permuted weights (clin0_cl)
+    int cnn_band_R = 0;                    // output rows per band of conv_1, 0: plan not available
+    int cnn_cp[2] = {0, 0};                // channels per cell of conv_0's / conv_1's output (padded to 16)
+    ConvLayer clin0_cl;
 
     // workspace
     void* ws = nullptr;
@@ -322,6 +329,25 @@ int build_cnn(kws_handle* h) {
         h->required.insert(std::string("layers.") + names[i] + ".bias");
         feat = outs[i];
         mx = std::max(mx, (size_t)feat);
+    }
+    // band plan for conv_1: stride 1, identity pool_1, conv_0's pooling fusable, a Linear behind it
+    const bool band_off = std::getenv("KWS_CNN_BAND") && std::atoi(std::getenv("KWS_CNN_BAND")) == 0;   // A/B and tests
+    if (d.n_conv == 2 && !band_off && h->lw_mode == LW_TILED && d.conv[1].stride_h == 1 && d.conv[1].stride_w == 1 &&
+        d.pool_kh[1] * d.pool_kw[1] == 1 && d.pool_kh[0] * d.pool_kw[0] <= 16 && !h->clin.empty()) {
+        const int C0 = h->cnn_shape[1][0], H1 = h->cnn_shape[1][1], W1 = h->cnn_shape[1][2];
+        const int C1 = d.conv[1].out_channels, mh = conv_band_mh(C1);
+        const int R = (mh == 2 || mh == 3) ? conv_band_rows(C0, C1, H1, W1, d.conv[1].kernel_h, d.conv[1].kernel_w) : 0;
+        if (R > 0) {
+            h->cnn_band_R = R;
+            h->cnn_cp[0] = (C0 + 15) / 16 * 16;
+            h->cnn_cp[1] = (C1 + 15) / 16 * 16;
+            const ConvGeom& g1 = h->cconv[1].g;
+            const int kcl = g1.Ho * g1.Wo * h->cnn_cp[1];
+            h->clin0_cl.g = make_geom(1, h->clin[0].g.Cout, 1, kcl, 1, 1, 0, 0, 1, 1, 0);
+            set_spatial(h->clin0_cl.g, 0, 1, kcl);
+            h->clin0_cl.has_bias = true;
+            mx = std::max(mx, std::max((size_t)H1 * W1 * h->cnn_cp[0], (size_t)kcl));
+        }
     }
     h->cnn_max_elems = mx;
     return KWS_OK;
@@ -538,10 +564,12 @@ int plan_ksplit(const ConvGeom& g, int nb, int steps) {
 
 size_t cnn_partial_bytes(const kws_handle* h, int cb) {
     size_t mx = 0;
-    for (const auto& L : h->clin) {
+    auto one = [&](const ConvLayer& L) {
         const int ks = std::max(plan_ksplit(L.g, cb, L.g.ksteps), plan_ksplit(L.g, cb, std::max(L.g.x_ksteps, 1)));
         if (ks > 1) mx = std::max(mx, (size_t)ks * cb * L.g.Cout * L.g.Ho * L.g.Wo * 4);
-    }
+    };
+    for (const auto& L : h->clin) one(L);
+    if (h->cnn_band_R > 0) one(h->clin0_cl);
     return align256(mx);
 }
 
@@ -754,6 +782,13 @@ int launch_conv_auto(const ConvLayer& L, ConvGeom g, ConvArgs a, int nb, float* 
     return launch_layer(L, g, a, s, terms);
 }
 
+// The band plan needs fp16-part operands (modes 6 / 16); the other dtypes and the range-free second pass keep the generic kernels
+bool cnn_band_plan(const kws_handle* h, int mode) {
+    int f16, terms;
+    decode_mode(mode, f16, terms);
+    return h->cnn_band_R > 0 && f16 && h->cconv[0].use_x && h->clin0_cl.use_x && h->cconv[1].apk_band.p != nullptr;
+}
+
 int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
     const kws_model_desc& d = h->d;
     if (T != d.time) return fail(KWS_EINVAL, "CNN was built for a different number of frames (config[\"time\"])");
@@ -769,7 +804,45 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             const float* cur = feat + (size_t)b0 * d.time * d.freq;
             // the feature maps come from the caller: the first pass checks them like any stored activation
             if (rg.flag && !rg.gated) HIP_TRY(launch_range_check(cur, (long long)nb * d.time * d.freq, s, rg));
-            for (int i = 0; i < d.n_conv; ++i) {
+            int m_f16, m_terms;
+            decode_mode(terms, m_f16, m_terms);
+            size_t first_lin = 0;
+            if (cnn_band_plan(h, terms)) {
+                // conv_0 (+ fused MaxPool) writes channels-last cells -- fp32, or fp16 with single-term products -- conv_1 runs
+                // from LDS-staged bands of them (conv_band.hip), the first Linear reads conv_1's channels-last output
+                ConvGeom g0 = h->cconv[0].g;
+                g0.B = nb;
+                if (d.pool_kh[0] * d.pool_kw[0] >= 2) {
+                    g0.pool_h = d.pool_kh[0];
+                    g0.pool_w = d.pool_kw[0];
+                }
+                g0.out_cl = m_terms == 1 ? 2 : 1;
+                g0.out_cp = h->cnn_cp[0];
+                ConvArgs a0{cur, Q, h->cconv[0].apk.as<float>(), nullptr, h->cconv[0].bias.as<float>(), nullptr, nullptr, rg};
+                int rcb = launch_layer(h->cconv[0], g0, a0, s, terms);
+                if (rcb) return rcb;
+                const ConvGeom& g1 = h->cconv[1].g;
+                BandConvParams bp{};
+                bp.in = Q; bp.out = P;
+                bp.apk = h->cconv[1].apk_band.as<unsigned short>();
+                bp.bias = h->cconv[1].bias.as<float>();
+                bp.B = nb; bp.H = g1.H; bp.W = g1.W; bp.Cpi = h->cnn_cp[0];
+                bp.Ho = g1.Ho; bp.Wo = g1.Wo; bp.Cout = g1.Cout; bp.Cpo = h->cnn_cp[1];
+                bp.kh = g1.kh; bp.kw = g1.kw; bp.ksteps = (g1.kh * g1.kw * (bp.Cpi / 8) + 3) / 4;
+                bp.R = h->cnn_band_R; bp.nbands = (g1.Ho + bp.R - 1) / bp.R;
+                bp.terms = m_terms; bp.inv_scale = 1.0f / h->cconv[1].band_scale; bp.relu = 1; bp.rg = rg;
+                HIP_TRY(launch_conv_band(bp, s));
+                ConvGeom gl = h->clin0_cl.g;
+                gl.B = nb;
+                const bool last = h->clin.size() == 1;
+                float* dst = last ? logits + (size_t)b0 * d.n_labels : Q;
+                ConvArgs al{P, dst, h->clin0_cl.apk.as<float>(), nullptr, h->clin[0].bias.as<float>(), nullptr, nullptr, rg};
+                rcb = launch_conv_auto(h->clin0_cl, gl, al, nb, part, part_bytes, s, terms);
+                if (rcb) return rcb;
+                cur = dst;
+                first_lin = 1;
+            }
+            for (int i = 0; i < (first_lin ? 0 : d.n_conv); ++i) {
                 ConvGeom g = h->cconv[i].g;
                 g.B = nb;
                 float* conv_out_buf = other(cur);
@@ -791,7 +864,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                 HIP_TRY(launch_pool(conv_out_buf, pooled, nb * g.Cout, g.Ho, g.Wo, d.pool_kh[i], d.pool_kw[i], 1, s, rg));
                 cur = pooled;
             }
-            for (size_t i = 0; i < h->clin.size(); ++i) {
+            for (size_t i = first_lin; i < h->clin.size(); ++i) {
                 ConvGeom g = h->clin[i].g;
                 g.B = nb;
                 const bool last = i + 1 == h->clin.size();
@@ -845,7 +918,7 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
             if ((rc = run_resnet_layerwise(h, feat, B, T, logits, ws_act, s))) return rc;
         }
     } else if (h->plan == PLAN_CNN) {
-        h->last_plan = "layerwise";
+        h->last_plan = cnn_band_plan(h, dtype_terms(h->d.dtype)) ? "cnn_band" : "layerwise";
         if ((rc = run_cnn(h, feat, B, T, logits, ws_act, s))) return rc;
     } else {
         return fail(KWS_EUNSUPPORTED, "handle was created with family KWS_MODEL_NONE (front end only)");
@@ -970,6 +1043,12 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
             if (std::strcmp(field, "weight") == 0) {
                 if ((rc = need((size_t)L.g.Cout * L.g.Cin * L.g.kh * L.g.kw))) return rc;
                 if ((rc = upload_packed(L, src, h->lw_mode))) return rc;
+                if (idx == 1 && h->cnn_band_R > 0) {   // the same weights in conv_band.hip's fragment order
+                    std::vector<unsigned short> pkb;
+                    L.band_scale = weight_scale_pow2(src, (size_t)L.g.Cout * L.g.Cin * L.g.kh * L.g.kw);
+                    pack_conv_band_weights(L.g.Cin, L.g.Cout, L.g.kh, L.g.kw, src, L.band_scale, pkb);
+                    if ((rc = L.apk_band.upload(pkb.data(), pkb.size() * sizeof(unsigned short)))) return rc;
+                }
             } else {
                 if ((rc = need(L.g.Cout))) return rc;
                 if ((rc = L.bias.upload(src, bytes))) return rc;
@@ -983,6 +1062,19 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
             if (std::strcmp(field, "weight") == 0) {
                 if ((rc = need((size_t)L.g.Cout * L.g.kw))) return rc;
                 if ((rc = upload_packed(L, src, h->lw_mode))) return rc;
+                if (li == 0 && h->cnn_band_R > 0) {
+                    // the band plan hands this Linear conv_1's output as (position, channel padded to 16) instead of the
+                    // reference's flatten order (channel, position): same weights, columns permuted, zeros for the padding
+                    ConvLayer& Lc = h->clin0_cl;
+                    const ConvGeom& g1 = h->cconv[1].g;
+                    const int npos = g1.Ho * g1.Wo, cp1 = h->cnn_cp[1], C1 = g1.Cout;
+                    std::vector<float> wcl((size_t)L.g.Cout * Lc.g.kw, 0.f);
+                    for (int o = 0; o < L.g.Cout; ++o)
+                        for (int c = 0; c < C1; ++c)
+                            for (int ps = 0; ps < npos; ++ps)
+                                wcl[(size_t)o * Lc.g.kw + (size_t)ps * cp1 + c] = src[(size_t)o * L.g.kw + (size_t)c * npos + ps];
+                    if ((rc = upload_packed(Lc, wcl.data(), h->lw_mode))) return rc;
+                }
             } else {
                 if ((rc = need(L.g.Cout))) return rc;
                 if ((rc = L.bias.upload(src, bytes))) return rc;

@@ -249,6 +249,8 @@ struct ConvGeom {
     int pool_h, pool_w;    // conv_bf16x6_kernel only: fused MaxPool window (stride = window, floor), <= 16 members; 0 / 1 = none
     int ksplit;            // > 1: K range split over blockIdx.z (flat Cin == 1 mode only); partial sums go to ConvArgs::partial
     int ksteps_split;      // k-steps per split
+    int out_cl;            // conv_bf16x6_kernel only: 1 = write channels-last fp32 (B, npc, out_cp), 2 = the same as fp16 (for conv_band.hip);
+    int out_cp;            // channels of a cell (Cout padded to 16, zeros in the padding); no split-K / accumulate / border then
 };
 struct ConvArgs {
     const float* in;       // (B, Cin, H, W)
@@ -276,7 +278,15 @@ constexpr int T3_TILE_P_F16 = 320;     // two parts or one (fp16 default, bf16x3
 constexpr int T3_TILE_P_F16_NARROW = 192;   // the same, 17-24 channels: 3 tiles per wave, three workgroups per CU (+14 % measured)
 // parts of an operand that the LDS cell holds = parts that take part in the products (terms: 6 / 3 / 1 products per fp32 product)
 constexpr int t3_lds_parts(bool f16, int terms) { return f16 ? (terms >= 3 ? 2 : 1) : (terms == 6 ? 3 : (terms == 3 ? 2 : 1)); }
-constexpr int t3_tile_positions(int parts, int nb) { return parts >= 3 ? T3_TILE_P : (nb <= 3 ? T3_TILE_P_F16_NARROW : T3_TILE_P_F16); }
+#ifndef T3_S16_TILE
+#define T3_S16_TILE T3_TILE_P_F16      // A/B knob: positions per workgroup with 16-bit tensors (one part), 41-48 channels
+#endif
+#ifndef T3_S16_WGS
+#define T3_S16_WGS 3                   // A/B knob: workgroups per CU the single-part kernel is compiled for
+#endif
+constexpr int t3_tile_positions(int parts, int nb) {
+    return parts >= 3 ? T3_TILE_P : (nb <= 3 ? T3_TILE_P_F16_NARROW : (parts == 1 ? T3_S16_TILE : T3_TILE_P_F16));
+}
 struct TileConvParams {
     // Activations are fp32, except with single-term products (terms == 1: the `bf16` / `fp16` dtypes), where the three tensors hold
     // 16-bit values of the operand type (bf16, or fp16 when f16 is set): staging is then a plain copy and HBM traffic halves.
@@ -308,6 +318,25 @@ bool conv3x3_tile_supported(int C, int Cout, int Ws);
 void build_tile_conv_table(int H, int W, int ld_in, int ld_out, int ld_res, std::vector<int>& tab, int& cpc_in, int& cpc_out, int& cpc_res);
 void pack_conv3x3_tile_weights_f16(int C, const float* w /*C,C,3,3*/, float scale, std::vector<unsigned short>& dst);
 hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
+// LDS-staged band convolution for the second conv of the cnn-* models (conv_band.hip): stride 1, no padding, bias + ReLU
+struct BandConvParams {
+    const void* in;        // channels-last (B, H, W, Cpi): fp32, or fp16 when terms == 1; channels >= Cin hold zeros
+    float* out;            // channels-last fp32 (B, Ho, Wo, Cpo), zeros in the padding
+    const unsigned short* apk;   // pack_conv_band_weights
+    const float* bias;     // (Cout)
+    int B, H, W, Cpi, Ho, Wo, Cout, Cpo;
+    int kh, kw, ksteps;    // ksteps = ceil(kh * kw * Cpi / 32)
+    int R, nbands;         // output rows per workgroup (conv_band_rows), ceil(Ho / R)
+    int terms;             // 3: two-part fp16 operands (fp32-accurate); 1: one part (`fp16` dtype, fp16 input tensor)
+    float inv_scale;       // 2^-S of the weights
+    int relu;
+    RangeGate rg;
+};
+constexpr int conv_band_mh(int Cout) { return ((Cout + 15) / 16 + 1) / 2; }   // channel tiles per wave (two wave rows)
+int conv_band_rows(int Cin, int Cout, int H, int W, int kh, int kw);          // 0: layer not supported
+size_t conv_band_lds_bytes(int Cpi, int W, int kh, int kw, int R, int parts);
+void pack_conv_band_weights(int Cin, int Cout, int kh, int kw, const float* w, float scale, std::vector<unsigned short>& dst);
+hipError_t launch_conv_band(const BandConvParams& p, hipStream_t s);
 // fp32 (B, C, H, W) -> pooled (stride = window, floor; 1 x 1 = transpose only) channels-last (B, H/kh, W/kw, cp) fp32
 hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, int W, int kh, int kw, int is_max, int cp,
                              hipStream_t s, RangeGate rg = RangeGate{nullptr, 0});

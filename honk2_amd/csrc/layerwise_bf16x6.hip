@@ -262,6 +262,50 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
 #undef XLOADB
 #undef XCOMPUTE
 
+    if (gm.out_cl) {   // channels-last output (B, npc, out_cp) for conv_band.hip: fp32 or fp16 cells, exact zeros in the channel padding
+        float amax_cl = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int co0 = ((int)blockIdx.y * MT + m) * 16 + 4 * g;
+            if (co0 >= gm.out_cp) continue;
+            f32x4 bv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = (a.bias && co0 + r < gm.Cout) ? a.bias[co0 + r] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (nmem ? (j > 0 || n0 + pcol >= ntot) : !valid[j]) continue;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x;
+                    if (!nmem) x = acc[m][j][r];
+                    else if (MULTI) x = best[MULTI ? m : 0][r];
+                    else {
+                        x = acc[m][0][r];
+#pragma unroll
+                        for (int jj = 1; jj < 4; ++jj)
+                            if (jj < nmem) x = fmaxf(x, acc[m][jj][r]);
+                    }
+                    x = fmaf(x, gm.x_inv_scale, bv[r]);
+                    if (gm.relu) x = fmaxf(x, 0.f);
+                    v[r] = co0 + r < gm.Cout ? x : 0.f;
+                    amax_cl = fmaxf(amax_cl, fabsf(v[r]));
+                }
+                const size_t o = ((size_t)bidx[j] * npc + pos[j]) * gm.out_cp + co0;
+                if (gm.out_cl == 1) *reinterpret_cast<f32x4*>(a.out + o) = v;
+                else {
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                    const u32x2_ pk = {__builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[0], v[1]}, f16x2)),
+                                       __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[2], v[3]}, f16x2))};
+                    *reinterpret_cast<u32x2_*>(reinterpret_cast<unsigned short*>(a.out) + o) = pk;
+                }
+            }
+        }
+        range_note(a.rg, amax_cl);
+        return;
+    }
+
     int bmask[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -356,6 +400,8 @@ hipError_t launch_conv_bf16x6(const ConvGeom& g, const ConvArgs& a, hipStream_t 
     if (g.B <= 0) return hipSuccess;
     if (g.pool_h * g.pool_w > 1 && (g.pool_h * g.pool_w > 16 || g.ksplit > 1 || g.accumulate || a.border ||
                                     g.Ho < g.pool_h || g.Wo < g.pool_w))
+        return hipErrorInvalidValue;
+    if (g.out_cl && (g.ksplit > 1 || g.accumulate || a.border || g.out_cp % 16 || g.out_cp < g.Cout || g.out_cp > g.mtiles * 16))
         return hipErrorInvalidValue;
     switch (g.x_mt) {
         case 1: return launch_x_mt<1>(g, a, s);

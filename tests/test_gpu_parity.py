@@ -153,7 +153,9 @@ def test_model_logits_match_reference(torch_cuda, fname):
     assert np.abs(got - want).max() < LOGIT_TOL, (tag, np.abs(got - want).max())
     assert (got.argmax(1) == want.argmax(1)).all()
     assert model.num_params() == int(z["num_params"])
-    assert model.plan_name() == ("res8_fused" if tag == "resnet__res8" else "resnet_tiled" if name == "ResNet" else "layerwise")
+    # two-conv CNNs: conv_1 from LDS-staged bands (conv_band.hip); single-conv CNNs: the generic layer-wise kernels
+    assert model.plan_name() == ("res8_fused" if tag == "resnet__res8" else "resnet_tiled" if name == "ResNet" else
+                                 "cnn_band" if "conv_1" in cfg else "layerwise")
 
 
 @pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_cnn__cnn-trad-pool2.npz", "model_resnet__res8.npz"])
@@ -636,17 +638,23 @@ def test_reduced_precision_configs_at_baseline_batch(torch_cuda, fname, dtype, b
 
 
 @pytest.mark.parametrize("name,cfg_or_file,plan", [
+    ("CNN", "model_cnn__cnn-trad-pool2.npz", "cnn_band"),
+    ("CNN", "model_cnn__cnn-tstride4.npz", "cnn_band"),
+    ("CNN", "model_cnn__cnn-tpool2.npz", "cnn_band"),
     ("CNN", "model_cnn__cnn-trad-pool2.npz", "layerwise"),
     ("CNN", "model_cnn__cnn-tstride4.npz", "layerwise"),
     ("ResNet", {"n_feature_maps": 30, "n_layers": 5, "use_dilation": True, "n_labels": 12}, "layerwise"),
     ("ResNet", {"n_feature_maps": 45, "n_layers": 4, "use_dilation": True, "n_labels": 12}, "resnet_tiled"),
 ])
-def test_chunk_loops_against_the_oracle_at_1100_clips(torch_cuda, name, cfg_or_file, plan):
-    """1100 clips = one full 1024-clip chunk + a ragged second one through run_cnn, run_resnet_layerwise (generic kernels,
-    30 feature maps) and run_resnet_tiled, every logit compared with the fp32 CPU oracle (reference model/cnn.py:79-107,
+def test_chunk_loops_against_the_oracle_at_1100_clips(torch_cuda, monkeypatch, name, cfg_or_file, plan):
+    """1100 clips = one full 1024-clip chunk + a ragged second one through run_cnn (band plan: conv_band.hip behind a
+    channels-last conv_0, and the generic kernels with KWS_CNN_BAND=0), run_resnet_layerwise (generic kernels, 30 feature
+    maps) and run_resnet_tiled, every logit compared with the fp32 CPU oracle (reference model/cnn.py:79-107,
     model/resnet.py:38-60)."""
     torch = torch_cuda
     from oracle import models, weights
+    if name == "CNN" and plan == "layerwise":
+        monkeypatch.setenv("KWS_CNN_BAND", "0")
     if isinstance(cfg_or_file, str):
         _, _, cfg, _, _, _ = load_golden_model(cfg_or_file)
     else:

@@ -45,6 +45,7 @@ def main():
         batch = int(os.environ.get("KWS_BENCH_BATCH", "0")) or (8192 if MFLOP[tag] < 400 else 2048)
         x = torch.randn(batch, 101, 40, device=dev) * 2.5 + 0.65
         model(x[:64])
+        model(x)                       # full-batch warm-up: the workspace grows to its final size here, not in the timed calls
         torch.cuda.synchronize()
         reps = 3
         t0 = time.perf_counter()
