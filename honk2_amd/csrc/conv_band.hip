@@ -11,8 +11,13 @@
 //   * in: channels-last (B, H, W, Cpi), Cpi = input channels padded to 16 (the producer -- the generic kernel's channels-last
 //     epilogue, layerwise_bf16x6.hip -- writes exact zeros there); out: channels-last fp32 (B, Ho, Wo, Cpo); the Linear that
 //     follows reads it with its weight columns permuted to (position, channel) order on the host.
-//   * LDS cell = Cpi fp16 + 16 B of padding: the stride in dwords is 4 x odd, which spreads the 16 positions of a tile over all 64
-//     banks for ds_read_b128 (tools/lds_bank_model.py).  Two parts = two planes.
+//   * LDS image: [part][8-channel block][cell] x 16 B, cells = band rows x Wl (row stride padded), block planes a multiple of 16
+//     cells apart.  A ds_read_b128 of a B fragment is served in four 16-lane groups, each holding all 16 positions of the tile (8
+//     lanes of one k-group + the complementary 8 of the next one, whose plane starts 0 mod 256 B further on): it is conflict-free
+//     iff the tile's 16 cells are distinct mod 16 (res8_f16x3.hip, tools/r8_tiles.py).  Position tiles are therefore built on the
+//     host by residue class of the cell index (conv_band_plan picks the row stride Wl that balances the classes); the first
+//     version's cell-major image (tiles of 16 consecutive positions) spent 54 % of its LDS cycles in bank conflicts and left the
+//     matrix pipe 49 % busy.  Staging walks cells lane-fastest so that its 16-byte LDS writes are conflict-free too.
 //   * K order (tap, 8-channel block), four blocks per v_mfma_f32_16x16x32_f16 (one per 16-lane group); a k-step's (tap, block) of
 //     each lane group is a byte offset from a table in LDS.  Weights: fp16 parts scaled by 2^S in fragment order from L2 (shared by
 //     every workgroup), one k-step ahead.
@@ -46,6 +51,9 @@ __device__ __forceinline__ void band_split4(f32x4 x, u32x2 (&out)[2]) {
 }  // namespace
 
 constexpr int BAND_NT = 4;   // position tiles per wave (half a band)
+#ifndef BAND_APF
+#define BAND_APF 3            // k-steps of weight-fragment look-ahead (A/B knob)
+#endif
 
 // MH: channel tiles per wave (the layer has up to 2 MH); TERMS: 3 (two-part operands, fp32-accurate) or 1 (fp16 tensor in, one part)
 template <int MH, int TERMS>
@@ -54,6 +62,13 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
     constexpr bool S16 = TERMS == 1;
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
+#ifdef BAND_TIMING   // 100 MHz wall-clock stamps of this workgroup's phases (tools/band_phases.py)
+    unsigned long long bts[6];
+#define BAND_TS(i) bts[i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define BAND_TS(i)
+#endif
+    BAND_TS(0)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,60 +78,75 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
     const int r0 = band * p.R;                       // first output row = first input row of the band
     const int rows_out = min(p.R, p.Ho - r0);
     const int rows_in = p.R + p.kh - 1;
-    const int cellb = p.Cpi * 2 + 16;                // LDS bytes per cell and part
-    const int ncell = rows_in * p.W;
-    const int plane = ncell * cellb;
-    const int ktab_off = NP * plane;                 // int[(ksteps + 2) * 4]
     const int nbi = p.Cpi / 8;
+    const int planeb = p.PS * 16;                    // bytes per 8-channel block plane
+    const int partb = nbi * planeb;                  // bytes per part
+    const int ktab_off = NP * partb;                 // int[(ksteps + 2) * 4]
 
     // ---------------------------------------------------------------- k-step table + staging
     for (int i = tid; i < (p.ksteps + 2) * 4; i += 256) {
         const int tap = i / nbi, cb = i - tap * nbi;
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        reinterpret_cast<int*>(lds + ktab_off)[i] = tap < p.kh * p.kw ? (ky * p.W + kx) * cellb + cb * 16 : 0;   // (padding blocks carry zero weights)
+        reinterpret_cast<int*>(lds + ktab_off)[i] = tap < p.kh * p.kw ? cb * planeb + (ky * p.Wl + kx) * 16 : 0;   // (padding blocks carry zero weights)
     }
     {
-        const int nq = S16 ? p.Cpi / 8 : p.Cpi / 4;              // 16-byte chunks per global cell
+        // One wave-level load = 16 consecutive source cells (lanes 0-15) x four consecutive 16-byte chunks of each (lane >> 4): 64
+        // contiguous bytes per cell for the vector-memory path, and every 16-lane group writes 16 consecutive cells of one block
+        // plane -- conflict-free LDS stores (chunk-fastest lanes put the 16 chunks of a cell on four banks; cell-fastest lanes
+        // over a single chunk touch 64 cache lines per load).
         const int gcell = S16 ? p.Cpi * 2 : p.Cpi * 4;
         const char* src = reinterpret_cast<const char*>(p.in) + ((size_t)b * p.H + r0) * p.W * gcell;
-        const int nchunk = ncell * nq;
-        const int last = ((p.H - r0) * p.W) * nq - 1;            // rows past the input feed only outputs that are never stored: clamp
-        constexpr int UNR = 6;
-        for (int c0 = tid; c0 < nchunk; c0 += UNR * 256) {
+        const int nsrc = rows_in * p.W;
+        const int last = (p.H - r0) * p.W - 1;                   // rows past the input feed only outputs that are never stored: clamp
+        const int nch = S16 ? p.Cpi / 8 : p.Cpi / 4;             // 16-byte chunks per global cell
+        const int nqq = (nch + 3) / 4;                           // chunk quads per cell (the last one may be partial with fp16 tensors)
+        const int ncg = (nsrc + 15) / 16;
+        const int nit = ncg * nqq;                               // wave-level items
+        const int lc = lane & 15, lq = lane >> 4;
+        constexpr int UNR = 4;
+        for (int i0 = w; i0 < nit; i0 += UNR * 4) {
             f32x4 v[UNR];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)min(c0 + u * 256, last) * 16);
+            int dst[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const int c = c0 + u * 256;
-                if (c < nchunk) {
-                    const int cell = c / nq, q = c - cell * nq;
-                    if (S16) {
-                        *reinterpret_cast<f32x4*>(lds + cell * cellb + q * 16) = v[u];
-                    } else {
-                        u32x2 pr[2];
-                        band_split4(v[u], pr);
-                        *reinterpret_cast<u32x2*>(lds + cell * cellb + q * 8) = pr[0];
-                        *reinterpret_cast<u32x2*>(lds + plane + cell * cellb + q * 8) = pr[1];
-                    }
+                const int i = min(i0 + u * 4, nit - 1);
+                const int cg = i / nqq, qq = i - cg * nqq;
+                const int sc = cg * 16 + lc, q = qq * 4 + lq;
+                const int row = sc / p.W, x = sc - row * p.W;
+                // fp32: chunk q = channels 4q..4q+3 -> block q / 2, half q & 1;  fp16: chunk q = block q
+                dst[u] = (sc < nsrc && q < nch) ? (S16 ? q * planeb : (q >> 1) * planeb + (q & 1) * 8) + (row * p.Wl + x) * 16 : -1;
+                v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)min(sc, last) * gcell + min(q, nch - 1) * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (i0 + u * 4 >= nit || dst[u] < 0) continue;
+                if (S16) {
+                    *reinterpret_cast<f32x4*>(lds + dst[u]) = v[u];
+                } else {
+                    u32x2 pr[2];
+                    band_split4(v[u], pr);
+                    *reinterpret_cast<u32x2*>(lds + dst[u]) = pr[0];
+                    *reinterpret_cast<u32x2*>(lds + partb + dst[u]) = pr[1];
                 }
             }
         }
     }
 
-    // this lane's output positions: tile j of this wave = positions (wn * BAND_NT + j) * 16 + pcol of the band, row-major over (R, Wo)
-    const int npos = rows_out * p.Wo;
+    // this lane's output positions: tile t = wn * nth + j of the layer's position table (conv_band_plan), entry {cell, oy << 16 | ox}
+    const int nth = (p.ntiles + 1) >> 1;
     int lbase[BAND_NT], opos[BAND_NT];
-    const int ntile = min(BAND_NT, max(0, (npos + 15) / 16 - wn * BAND_NT));   // tiles of this wave that hold any valid position (uniform)
+    const int ntile = min(nth, max(0, p.ntiles - wn * nth));     // tiles of this wave (uniform)
 #pragma unroll
     for (int j = 0; j < BAND_NT; ++j) {
-        const int ps = (wn * BAND_NT + j) * 16 + pcol;
-        const int pc = min(ps, npos - 1);
-        const int oy = pc / p.Wo, ox = pc - oy * p.Wo;
-        lbase[j] = (oy * p.W + ox) * cellb;
-        opos[j] = ps < npos ? (r0 + oy) * p.Wo + ox : -1;
+        const int t = min(wn * nth + j, p.ntiles - 1);
+        const int cellv = p.postab[(t * 16 + pcol) * 2], yx = p.postab[(t * 16 + pcol) * 2 + 1];
+        const int oy = yx >> 16, ox = yx & 0xffff;
+        lbase[j] = cellv * 16;
+        opos[j] = (j < ntile && yx >= 0 && oy < rows_out) ? (r0 + oy) * p.Wo + ox : -1;
     }
+    BAND_TS(1)
     __syncthreads();
+    BAND_TS(2)
 
     // ---------------------------------------------------------------- k-loop
     f32x4 acc[MH][BAND_NT];
@@ -136,56 +166,75 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
 #define BLOADB(BR, J, KOFF)                                                                                \
     {                                                                                                      \
         const int ad_ = lbase[J] + (KOFF);                                                                 \
-        _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) BR[pt] = *reinterpret_cast<const u32x4*>(lds + pt * plane + ad_); \
+        _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) BR[pt] = *reinterpret_cast<const u32x4*>(lds + pt * partb + ad_); \
     }
-#define BTERMS(AR, BR, C_)                    \
-    {                                         \
-        if (TERMS >= 3) {                     \
-            BMF(AR[1], BR[0], C_);            \
-            BMF(AR[0], BR[1], C_);            \
-        }                                     \
-        BMF(AR[0], BR[0], C_);                \
+    // one term of a tile pair: four independent accumulator chains (two channel tiles x two position tiles; MH = 3: six) -- with one
+    // tile at a time an accumulator came round again after one other MFMA, inside the matrix pipe's own latency
+#define BTERM2(PA, PB, AR, B0, B1, J)                                                                      \
+    {                                                                                                      \
+        _Pragma("unroll") for (int m = 0; m < MH; ++m) BMF(AR[m][PA], B0[PB], acc[m][J]);                  \
+        _Pragma("unroll") for (int m = 0; m < MH; ++m) BMF(AR[m][PA], B1[PB], acc[m][(J) + 1]);            \
     }
-    // one k-step: B fragments one position tile ahead; BX holds tile 0 on entry, and tile 0 of the next step (offset KNEXT) on exit
-    // (BAND_NT is even: the two buffers keep their roles from step to step)
+#define BTERM1(PA, PB, AR, B0, J)                                                                          \
+    {                                                                                                      \
+        _Pragma("unroll") for (int m = 0; m < MH; ++m) BMF(AR[m][PA], B0[PB], acc[m][J]);                  \
+    }
+    // one k-step: B fragments one tile PAIR ahead; (bq0, bq1) hold tiles 0, 1 on entry and tiles 0, 1 of the next step (offset KNEXT)
+    // on exit (BAND_NT / 2 pairs per step is even: the buffers keep their roles from step to step)
 #define BSTEP(AR, KCUR, KNEXT)                                                                             \
     {                                                                                                      \
-        _Pragma("unroll") for (int j = 0; j < BAND_NT; ++j) {                                              \
-            u32x4 (&cur_)[NP] = (j & 1) ? bb1 : bb0;                                                       \
-            u32x4 (&nxt_)[NP] = (j & 1) ? bb0 : bb1;                                                       \
-            if (j + 1 < BAND_NT) BLOADB(nxt_, j + 1, KCUR) else BLOADB(nxt_, 0, KNEXT)                     \
+        _Pragma("unroll") for (int jp = 0; jp < BAND_NT; jp += 2) {                                        \
+            u32x4 (&c0_)[NP] = (jp & 2) ? bq2 : bq0;                                                       \
+            u32x4 (&c1_)[NP] = (jp & 2) ? bq3 : bq1;                                                       \
+            u32x4 (&n0_)[NP] = (jp & 2) ? bq0 : bq2;                                                       \
+            u32x4 (&n1_)[NP] = (jp & 2) ? bq1 : bq3;                                                       \
+            if (jp + 2 < BAND_NT) {                                                                        \
+                if (jp + 2 < ntile) BLOADB(n0_, jp + 2, KCUR)                                              \
+                if (jp + 3 < ntile) BLOADB(n1_, jp + 3, KCUR)                                              \
+            } else {                                                                                       \
+                BLOADB(n0_, 0, KNEXT)                                                                      \
+                if (1 < ntile) BLOADB(n1_, 1, KNEXT)                                                       \
+            }                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                             \
-            if (j < ntile) {                                                                               \
-                _Pragma("unroll") for (int m = 0; m < MH; ++m) BTERMS(AR[m], cur_, acc[m][j])              \
+            if (jp + 1 < ntile) {                                                                          \
+                if (TERMS >= 3) { BTERM2(1, 0, AR, c0_, c1_, jp) BTERM2(0, 1, AR, c0_, c1_, jp) }          \
+                BTERM2(0, 0, AR, c0_, c1_, jp)                                                             \
+            } else if (jp < ntile) {                                                                       \
+                if (TERMS >= 3) { BTERM1(1, 0, AR, c0_, jp) BTERM1(0, 1, AR, c0_, jp) }                    \
+                BTERM1(0, 0, AR, c0_, jp)                                                                  \
             }                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                             \
         }                                                                                                  \
     }
-    static_assert(BAND_NT % 2 == 0, "fragment buffers keep their roles");
-    u32x4 a0[MH][NP], a1[MH][NP], bb0[NP], bb1[NP];
+    static_assert(BAND_NT % 4 == 0, "fragment buffers keep their roles");
+    // Weight fragments are requested BAND_APF k-steps ahead: a k-step is only 6 - 27 MFMAs (100 - 430 clocks) long, less than an L2
+    // round trip, and the fragments of a layer (320 - 640 KB) do not stay in the CU's L1.
+    u32x4 a[BAND_APF + 1][MH][NP], bq0[NP], bq1[NP], bq2[NP], bq3[NP];
     if (ntile > 0) {
         int kc = ktab[0];
-        BLOADA(a0, 0)
-        BLOADB(bb0, 0, kc)
-        for (int s = 0; s < p.ksteps; s += 2) {
-            int kn = ktab[4 * (s + 1)];
-            if (s + 1 < p.ksteps) BLOADA(a1, s + 1)
-            __builtin_amdgcn_sched_barrier(0);
-            BSTEP(a0, kc, kn)
-            if (s + 1 >= p.ksteps) break;
-            kc = kn;
-            kn = ktab[4 * (s + 2)];
-            if (s + 2 < p.ksteps) BLOADA(a0, s + 2)
-            __builtin_amdgcn_sched_barrier(0);
-            BSTEP(a1, kc, kn)
-            kc = kn;
+#pragma unroll
+        for (int u = 0; u < BAND_APF; ++u) BLOADA(a[u], min(u, p.ksteps - 1))
+        BLOADB(bq0, 0, kc)
+        BLOADB(bq1, 1, kc)
+        for (int s = 0; s < p.ksteps; s += BAND_APF + 1) {
+#pragma unroll
+            for (int u = 0; u <= BAND_APF; ++u) {
+                if (s + u >= p.ksteps) break;
+                const int kn = ktab[4 * (s + u + 1)];
+                BLOADA(a[(u + BAND_APF) % (BAND_APF + 1)], min(s + u + BAND_APF, p.ksteps - 1))
+                __builtin_amdgcn_sched_barrier(0);
+                BSTEP(a[u], kc, kn)
+                kc = kn;
+            }
         }
     }
 #undef BLOADA
 #undef BLOADB
-#undef BTERMS
+#undef BTERM2
+#undef BTERM1
 #undef BSTEP
 
+    BAND_TS(3)
     // ---------------------------------------------------------------- epilogue: bias, ReLU, channels-last fp32 stores
     float amax = 0.f;
     float* const outb = p.out + (size_t)b * p.Ho * p.Wo * p.Cpo;
@@ -211,33 +260,75 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
         }
     }
     range_note(p.rg, amax);
+#ifdef BAND_TIMING
+    BAND_TS(4)
+    if (p.dbg_ts && lane == 0 && blockIdx.x < 8192) {     // 4 waves x 8 words per workgroup
+        unsigned long long* o = p.dbg_ts + ((size_t)blockIdx.x * 4 + w) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = bts[i];
+        o[5] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    }
+#endif
 }
 
-size_t conv_band_lds_bytes(int Cpi, int W, int kh, int kw, int R, int parts) {
+size_t conv_band_lds_bytes(int Cpi, int kh, int kw, int PS, int parts) {
     const int nbi = Cpi / 8, ksteps = (kh * kw * nbi + 3) / 4;
-    return (size_t)parts * (R + kh - 1) * W * (Cpi * 2 + 16) + (size_t)(ksteps + 2) * 16;
+    return (size_t)parts * nbi * PS * 16 + (size_t)(ksteps + 2) * 16;
 }
 
-// Rows per band: the largest R whose band fits half a CU's LDS with two-part cells and 2 x BAND_NT position tiles, weighted by how
-// full its tiles are.  0: the layer does not fit this kernel.
-int conv_band_rows(int Cin, int Cout, int H, int W, int kh, int kw) {
-    const int Cpi = (Cin + 15) / 16 * 16, Ho = H - kh + 1, Wo = W - kw + 1;
-    if (Cin < 16 || Cout > 96 || Ho < 1 || Wo < 1 || Wo > 16 * 2 * BAND_NT) return 0;
-    int best = 0;
-    double best_eff = 0.0;
-    for (int R = 1; R <= Ho && R * Wo <= 16 * 2 * BAND_NT; ++R) {
-        if (conv_band_lds_bytes(Cpi, W, kh, kw, R, 2) > 80 * 1024 - 256) break;
-        // useful MFMA share: positions over the tile slots of the slower wave pair, rows over the rows the bands cover, and the
-        // halo rows each band re-reads count against small R through the staging cost
-        const int nb = (Ho + R - 1) / R;
-        const int tiles = (R * Wo + 15) / 16, slots = 2 * ((tiles + 1) / 2);
-        const double eff = (double)(Ho * Wo) / ((double)nb * slots * 16) * ((double)R / (R + 0.25 * (kh - 1)));
-        if (eff > best_eff) {
-            best_eff = eff;
-            best = R;
+// Position tiles of an R-row band whose LDS rows are Wl cells apart: tile t takes the t-th position of every residue class of
+// cell = oy Wl + ox mod 16 (lane = class); a class that has run out leaves a pad lane, which clones another lane of its tile (same
+// address: a broadcast) and stores nothing.  Returns the number of tiles.
+static int band_tiles(int R, int Wo, int Wl, std::vector<int>* tab) {
+    std::vector<int> cls[16];
+    for (int oy = 0; oy < R; ++oy)
+        for (int ox = 0; ox < Wo; ++ox) cls[(oy * Wl + ox) & 15].push_back((oy << 16) | ox);
+    size_t nt = 0;
+    for (const auto& c : cls) nt = std::max(nt, c.size());
+    if (tab) {
+        tab->assign(nt * 16 * 2, 0);
+        for (size_t t = 0; t < nt; ++t) {
+            int clone = -1;
+            for (int r = 0; r < 16 && clone < 0; ++r)
+                if (t < cls[r].size()) clone = cls[r][t];
+            for (int r = 0; r < 16; ++r) {
+                const bool have = t < cls[r].size();
+                const int yx = have ? cls[r][t] : clone;
+                (*tab)[(t * 16 + r) * 2] = (yx >> 16) * Wl + (yx & 0xffff);
+                (*tab)[(t * 16 + r) * 2 + 1] = have ? yx : -1;
+            }
         }
     }
-    return best;
+    return (int)nt;
+}
+
+// Rows per band R and LDS row stride Wl: the band must fit half a CU's LDS with two-part operands and 2 x BAND_NT position tiles;
+// among those, the best share of useful MFMA slots (tile fill x rows covered, halo rows re-staged by every band counted against
+// small R).  false: the layer does not fit this kernel.
+bool conv_band_plan(int Cin, int Cout, int H, int W, int kh, int kw, BandPlan& out) {
+    const int Cpi = (Cin + 15) / 16 * 16, Ho = H - kh + 1, Wo = W - kw + 1, mh = conv_band_mh(Cout);
+    out = BandPlan{};
+    if (Cin < 16 || (mh != 2 && mh != 3) || Ho < 1 || Wo < 1 || Wo > 0xffff) return false;
+    double best_eff = 0.0;
+    for (int R = 1; R <= Ho; ++R) {
+        bool any = false;
+        for (int Wl = W; Wl < W + 16; ++Wl) {
+            const int PS = ((R + kh - 1) * Wl + 15) / 16 * 16;
+            if (conv_band_lds_bytes(Cpi, kh, kw, PS, 2) > 80 * 1024 - 256) continue;
+            const int nt = band_tiles(R, Wo, Wl, nullptr);
+            if (nt > 2 * BAND_NT) continue;
+            any = true;
+            const int nb = (Ho + R - 1) / R, slots = 2 * ((nt + 1) / 2);
+            const double eff = (double)(Ho * Wo) / ((double)nb * slots * 16) * ((double)R / (R + 0.25 * (kh - 1)));
+            if (eff > best_eff + 1e-9) {
+                best_eff = eff;
+                out.R = R; out.Wl = Wl; out.PS = PS; out.ntiles = nt;
+            }
+        }
+        if (!any && R * Wo > 16 * 2 * BAND_NT) break;
+    }
+    if (out.R == 0) return false;
+    band_tiles(out.R, Wo, out.Wl, &out.tab);
+    return true;
 }
 
 // weights (Cout, Cin, kh, kw) x scale -> two fp16 parts, [k-step][2 MH channel tiles][part][lane][8]; block 4 s + (lane >> 4) = (tap, 8-channel block)
@@ -264,7 +355,7 @@ void pack_conv_band_weights(int Cin, int Cout, int kh, int kw, const float* w, f
 
 template <int MH, int TERMS>
 static hipError_t launch_band_k(const BandConvParams& p, hipStream_t s) {
-    const size_t lds = conv_band_lds_bytes(p.Cpi, p.W, p.kh, p.kw, p.R, TERMS >= 3 ? 2 : 1);
+    const size_t lds = conv_band_lds_bytes(p.Cpi, p.kh, p.kw, p.PS, TERMS >= 3 ? 2 : 1);
     auto k = conv_band_kernel<MH, TERMS>;
     static DeviceOnce attr_once;   // per instantiation: allow > 64 KB of dynamic LDS
     if (attr_once.first()) {
@@ -278,8 +369,9 @@ static hipError_t launch_band_k(const BandConvParams& p, hipStream_t s) {
 hipError_t launch_conv_band(const BandConvParams& p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     const int mh = conv_band_mh(p.Cout);
-    if (p.R < 1 || p.Cpi % 16 || p.Cpo % 16 || p.Cpo < p.Cout || p.Cpo > 32 * mh || p.R * p.Wo > 16 * 2 * BAND_NT ||
-        (p.terms != 3 && p.terms != 1) || conv_band_lds_bytes(p.Cpi, p.W, p.kh, p.kw, p.R, 2) > 160 * 1024 - 512)
+    if (p.R < 1 || p.Cpi % 16 || p.Cpo % 16 || p.Cpo < p.Cout || p.Cpo > 32 * mh || p.ntiles < 1 || p.ntiles > 2 * BAND_NT ||
+        p.Wl < p.W || p.PS % 16 || p.PS < (p.R + p.kh - 1) * p.Wl || !p.postab || (p.terms != 3 && p.terms != 1) ||
+        conv_band_lds_bytes(p.Cpi, p.kh, p.kw, p.PS, 2) > 160 * 1024 - 512)
         return hipErrorInvalidValue;
     if (mh == 2) return p.terms == 3 ? launch_band_k<2, 3>(p, s) : launch_band_k<2, 1>(p, s);
     return p.terms == 3 ? launch_band_k<3, 3>(p, s) : launch_band_k<3, 1>(p, s);

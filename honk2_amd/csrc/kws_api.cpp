@@ -116,6 +116,8 @@ struct kws_handle {
     // "cnn_band" plan (fp16-part modes): conv_0 writes channels-last cells, conv_1 runs in conv_band.hip, the first Linear reads
     // its channels-last output through column-permuted weights (clin0_cl)
     int cnn_band_R = 0;                    // output rows per band of conv_1, 0: plan not available
+    BandPlan cnn_band;                     // conv_band_plan of conv_1
+    DevMem cnn_band_tab;                   // its position table
     int cnn_cp[2] = {0, 0};                // channels per cell of conv_0's / conv_1's output (padded to 16)
     ConvLayer clin0_cl;
 
@@ -335,10 +337,11 @@ int build_cnn(kws_handle* h) {
     if (d.n_conv == 2 && !band_off && h->lw_mode == LW_TILED && d.conv[1].stride_h == 1 && d.conv[1].stride_w == 1 &&
         d.pool_kh[1] * d.pool_kw[1] == 1 && d.pool_kh[0] * d.pool_kw[0] <= 16 && !h->clin.empty()) {
         const int C0 = h->cnn_shape[1][0], H1 = h->cnn_shape[1][1], W1 = h->cnn_shape[1][2];
-        const int C1 = d.conv[1].out_channels, mh = conv_band_mh(C1);
-        const int R = (mh == 2 || mh == 3) ? conv_band_rows(C0, C1, H1, W1, d.conv[1].kernel_h, d.conv[1].kernel_w) : 0;
-        if (R > 0) {
-            h->cnn_band_R = R;
+        const int C1 = d.conv[1].out_channels;
+        if (conv_band_plan(C0, C1, H1, W1, d.conv[1].kernel_h, d.conv[1].kernel_w, h->cnn_band)) {
+            int rcu = h->cnn_band_tab.upload(h->cnn_band.tab.data(), h->cnn_band.tab.size() * sizeof(int));
+            if (rcu) return rcu;
+            h->cnn_band_R = h->cnn_band.R;
             h->cnn_cp[0] = (C0 + 15) / 16 * 16;
             h->cnn_cp[1] = (C1 + 15) / 16 * 16;
             const ConvGeom& g1 = h->cconv[1].g;
@@ -830,8 +833,29 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                 bp.Ho = g1.Ho; bp.Wo = g1.Wo; bp.Cout = g1.Cout; bp.Cpo = h->cnn_cp[1];
                 bp.kh = g1.kh; bp.kw = g1.kw; bp.ksteps = (g1.kh * g1.kw * (bp.Cpi / 8) + 3) / 4;
                 bp.R = h->cnn_band_R; bp.nbands = (g1.Ho + bp.R - 1) / bp.R;
+                bp.Wl = h->cnn_band.Wl; bp.PS = h->cnn_band.PS; bp.ntiles = h->cnn_band.ntiles;
+                bp.postab = h->cnn_band_tab.as<int>();
                 bp.terms = m_terms; bp.inv_scale = 1.0f / h->cconv[1].band_scale; bp.relu = 1; bp.rg = rg;
+                // KWS_BAND_TIMING=<file> (timing builds only): phase stamps of the first chunk's band kernel (tools/band_phases.py)
+                static const char* band_file = std::getenv("KWS_BAND_TIMING");
+                static DevMem band_buf;
+                const bool band_this = band_file && b0 == 0 && !rg.gated;
+                if (band_this) {
+                    std::vector<unsigned long long> z((size_t)8192 * 4 * 8, 0ull);
+                    int rcz = band_buf.upload(z.data(), z.size() * 8);
+                    if (rcz) return rcz;
+                    bp.dbg_ts = band_buf.as<unsigned long long>();
+                }
                 HIP_TRY(launch_conv_band(bp, s));
+                if (band_this) {
+                    std::vector<unsigned long long> z((size_t)8192 * 4 * 8);
+                    HIP_TRY(hipStreamSynchronize(s));
+                    HIP_TRY(hipMemcpy(z.data(), band_buf.p, z.size() * 8, hipMemcpyDeviceToHost));
+                    if (FILE* f = std::fopen(band_file, "wb")) {
+                        std::fwrite(z.data(), 8, z.size(), f);
+                        std::fclose(f);
+                    }
+                }
                 ConvGeom gl = h->clin0_cl.g;
                 gl.B = nb;
                 const bool last = h->clin.size() == 1;

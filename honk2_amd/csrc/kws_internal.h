@@ -326,15 +326,22 @@ struct BandConvParams {
     const float* bias;     // (Cout)
     int B, H, W, Cpi, Ho, Wo, Cout, Cpo;
     int kh, kw, ksteps;    // ksteps = ceil(kh * kw * Cpi / 32)
-    int R, nbands;         // output rows per workgroup (conv_band_rows), ceil(Ho / R)
+    int R, nbands;         // output rows per workgroup (conv_band_plan), ceil(Ho / R)
+    int Wl, PS, ntiles;    // LDS row stride in cells, cells per block plane (multiple of 16), position tiles per band (<= 8)
+    const int* postab;     // [ntiles][16] x {LDS cell of the position, oy << 16 | ox, or -1 for a pad lane} (BandPlan::tab)
+    unsigned long long* dbg_ts;   // KWS_BAND_TIMING (with a -DBAND_TIMING build): phase stamps of the first 8192 workgroups, or nullptr
     int terms;             // 3: two-part fp16 operands (fp32-accurate); 1: one part (`fp16` dtype, fp16 input tensor)
     float inv_scale;       // 2^-S of the weights
     int relu;
     RangeGate rg;
 };
 constexpr int conv_band_mh(int Cout) { return ((Cout + 15) / 16 + 1) / 2; }   // channel tiles per wave (two wave rows)
-int conv_band_rows(int Cin, int Cout, int H, int W, int kh, int kw);          // 0: layer not supported
-size_t conv_band_lds_bytes(int Cpi, int W, int kh, int kw, int R, int parts);
+struct BandPlan {
+    int R = 0, Wl = 0, PS = 0, ntiles = 0;
+    std::vector<int> tab;
+};
+bool conv_band_plan(int Cin, int Cout, int H, int W, int kh, int kw, BandPlan& out);   // false: layer not supported
+size_t conv_band_lds_bytes(int Cpi, int kh, int kw, int PS, int parts);
 void pack_conv_band_weights(int Cin, int Cout, int kh, int kw, const float* w, float scale, std::vector<unsigned short>& dst);
 hipError_t launch_conv_band(const BandConvParams& p, hipStream_t s);
 // fp32 (B, C, H, W) -> pooled (stride = window, floor; 1 x 1 = transpose only) channels-last (B, H/kh, W/kw, cp) fp32
