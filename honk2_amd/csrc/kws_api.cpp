@@ -66,6 +66,7 @@ struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the l
     bool has_bias = false, has_border = false, use_x = false;   // use_x: bf16x6 kernel available for this layer
     DevMem apk_band;         // conv_band.hip fragments of a cnn-* conv_1 (fp16 parts x band_scale)
     float band_scale = 1.f;
+    DevMem apk_in1[2];       // conv_in1.hip fragments of a cnn-* conv_0 for IN1_MH3 / IN1_MH1 channel tiles per pass (x x_scale)
     std::vector<float> w_host;   // ResNet: raw weights kept until finalize() folds the previous BatchNorm in
 };
 
@@ -116,6 +117,9 @@ struct kws_handle {
     // "cnn_band" plan (fp16-part modes): conv_0 writes channels-last cells, conv_1 runs in conv_band.hip, the first Linear reads
     // its channels-last output through column-permuted weights (clin0_cl)
     int cnn_band_R = 0;                    // output rows per band of conv_1, 0: plan not available
+    bool cnn_in1 = false;                  // conv_0 runs in conv_in1.hip (LDS image of the clip) in the channels-last plans
+    bool cnn_cl1 = false;                  // single-conv model: conv_in1 -> clin0_cl ("cnn_in1" plan)
+    int cl_last[3] = {0, 0, 0};            // (channels, positions, channels per cell) of the tensor the first Linear reads
     BandPlan cnn_band;                     // conv_band_plan of conv_1
     DevMem cnn_band_tab;                   // its position table
     int cnn_cp[2] = {0, 0};                // channels per cell of conv_0's / conv_1's output (padded to 16)
@@ -350,7 +354,22 @@ int build_cnn(kws_handle* h) {
             set_spatial(h->clin0_cl.g, 0, 1, kcl);
             h->clin0_cl.has_bias = true;
             mx = std::max(mx, std::max((size_t)H1 * W1 * h->cnn_cp[0], (size_t)kcl));
+            h->cl_last[0] = C1; h->cl_last[1] = g1.Ho * g1.Wo; h->cl_last[2] = h->cnn_cp[1];
         }
+    }
+    const bool in1_off = std::getenv("KWS_CNN_IN1") && std::atoi(std::getenv("KWS_CNN_IN1")) == 0;   // A/B and tests
+    const bool in1_ok = !in1_off && !band_off && h->lw_mode == LW_TILED && conv_in1_supported(h->cconv[0].g, d.pool_kh[0], d.pool_kw[0]);
+    if (h->cnn_band_R > 0) h->cnn_in1 = in1_ok;
+    else if (d.n_conv == 1 && in1_ok && !h->clin.empty()) {   // single-conv models: the Linear reads conv_0's channels-last cells
+        const int C0 = h->cnn_shape[1][0], H1 = h->cnn_shape[1][1], W1 = h->cnn_shape[1][2];
+        h->cnn_in1 = h->cnn_cl1 = true;
+        h->cnn_cp[0] = (C0 + 15) / 16 * 16;
+        const int kcl = H1 * W1 * h->cnn_cp[0];
+        h->clin0_cl.g = make_geom(1, h->clin[0].g.Cout, 1, kcl, 1, 1, 0, 0, 1, 1, 0);
+        set_spatial(h->clin0_cl.g, 0, 1, kcl);
+        h->clin0_cl.has_bias = true;
+        mx = std::max(mx, (size_t)kcl);
+        h->cl_last[0] = C0; h->cl_last[1] = H1 * W1; h->cl_last[2] = h->cnn_cp[0];
     }
     h->cnn_max_elems = mx;
     return KWS_OK;
@@ -572,7 +591,7 @@ size_t cnn_partial_bytes(const kws_handle* h, int cb) {
         if (ks > 1) mx = std::max(mx, (size_t)ks * cb * L.g.Cout * L.g.Ho * L.g.Wo * 4);
     };
     for (const auto& L : h->clin) one(L);
-    if (h->cnn_band_R > 0) one(h->clin0_cl);
+    if (h->cnn_band_R > 0 || h->cnn_cl1) one(h->clin0_cl);
     return align256(mx);
 }
 
@@ -791,6 +810,12 @@ bool cnn_band_plan(const kws_handle* h, int mode) {
     decode_mode(mode, f16, terms);
     return h->cnn_band_R > 0 && f16 && h->cconv[0].use_x && h->clin0_cl.use_x && h->cconv[1].apk_band.p != nullptr;
 }
+// single-conv models: conv_0 from the LDS image (conv_in1.hip), channels-last cells straight into the permuted Linear
+bool cnn_in1_plan(const kws_handle* h, int mode) {
+    int f16, terms;
+    decode_mode(mode, f16, terms);
+    return h->cnn_cl1 && f16 && h->clin0_cl.use_x && h->cconv[0].apk_in1[0].p != nullptr;
+}
 
 int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
     const kws_model_desc& d = h->d;
@@ -810,20 +835,36 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             int m_f16, m_terms;
             decode_mode(terms, m_f16, m_terms);
             size_t first_lin = 0;
-            if (cnn_band_plan(h, terms)) {
-                // conv_0 (+ fused MaxPool) writes channels-last cells -- fp32, or fp16 with single-term products -- conv_1 runs
-                // from LDS-staged bands of them (conv_band.hip), the first Linear reads conv_1's channels-last output
-                ConvGeom g0 = h->cconv[0].g;
-                g0.B = nb;
-                if (d.pool_kh[0] * d.pool_kw[0] >= 2) {
-                    g0.pool_h = d.pool_kh[0];
-                    g0.pool_w = d.pool_kw[0];
+            const bool band = cnn_band_plan(h, terms), cl1 = cnn_in1_plan(h, terms);
+            if (band || cl1) {
+                // conv_0 (+ fused MaxPool) writes channels-last cells -- fp32, or fp16 with single-term products: from an LDS image
+                // of the clip (conv_in1.hip) where the layer fits it, else through the generic kernel's channels-last epilogue
+                int rcb;
+                if (h->cnn_in1) {
+                    const ConvGeom& g0 = h->cconv[0].g;
+                    In1ConvParams ip{};
+                    ip.feat = cur; ip.out = Q;
+                    ip.apk = h->cconv[0].apk_in1[m_terms == 1 ? 1 : 0].as<unsigned short>();
+                    ip.bias = h->cconv[0].bias.as<float>();
+                    ip.B = nb; ip.T = d.time; ip.F = d.freq; ip.Cout = g0.Cout; ip.Cp = h->cnn_cp[0]; ip.mtiles = g0.mtiles;
+                    ip.kh = g0.kh; ip.sh = g0.sh; ip.sw = g0.sw; ip.ph = d.pool_kh[0]; ip.pw = d.pool_kw[0];
+                    ip.Hq = g0.Ho / d.pool_kh[0]; ip.Wq = g0.Wo / d.pool_kw[0];
+                    ip.terms = m_terms; ip.inv_scale = 1.0f / h->cconv[0].x_scale; ip.relu = 1; ip.out_f16 = band && m_terms == 1; ip.rg = rg;
+                    HIP_TRY(launch_conv_in1(ip, s));
+                } else {
+                    ConvGeom g0 = h->cconv[0].g;
+                    g0.B = nb;
+                    if (d.pool_kh[0] * d.pool_kw[0] >= 2) {
+                        g0.pool_h = d.pool_kh[0];
+                        g0.pool_w = d.pool_kw[0];
+                    }
+                    g0.out_cl = (band && m_terms == 1) ? 2 : 1;   // fp16 cells only for conv_band.hip; a Linear reads fp32
+                    g0.out_cp = h->cnn_cp[0];
+                    ConvArgs a0{cur, Q, h->cconv[0].apk.as<float>(), nullptr, h->cconv[0].bias.as<float>(), nullptr, nullptr, rg};
+                    if ((rcb = launch_layer(h->cconv[0], g0, a0, s, terms))) return rcb;
                 }
-                g0.out_cl = m_terms == 1 ? 2 : 1;
-                g0.out_cp = h->cnn_cp[0];
-                ConvArgs a0{cur, Q, h->cconv[0].apk.as<float>(), nullptr, h->cconv[0].bias.as<float>(), nullptr, nullptr, rg};
-                int rcb = launch_layer(h->cconv[0], g0, a0, s, terms);
-                if (rcb) return rcb;
+                const float* lin_in = Q;
+                if (band) {
                 const ConvGeom& g1 = h->cconv[1].g;
                 BandConvParams bp{};
                 bp.in = Q; bp.out = P;
@@ -856,11 +897,13 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                         std::fclose(f);
                     }
                 }
+                lin_in = P;
+                }
                 ConvGeom gl = h->clin0_cl.g;
                 gl.B = nb;
                 const bool last = h->clin.size() == 1;
-                float* dst = last ? logits + (size_t)b0 * d.n_labels : Q;
-                ConvArgs al{P, dst, h->clin0_cl.apk.as<float>(), nullptr, h->clin[0].bias.as<float>(), nullptr, nullptr, rg};
+                float* dst = last ? logits + (size_t)b0 * d.n_labels : other(lin_in);
+                ConvArgs al{lin_in, dst, h->clin0_cl.apk.as<float>(), nullptr, h->clin[0].bias.as<float>(), nullptr, nullptr, rg};
                 rcb = launch_conv_auto(h->clin0_cl, gl, al, nb, part, part_bytes, s, terms);
                 if (rcb) return rcb;
                 cur = dst;
@@ -942,7 +985,7 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
             if ((rc = run_resnet_layerwise(h, feat, B, T, logits, ws_act, s))) return rc;
         }
     } else if (h->plan == PLAN_CNN) {
-        h->last_plan = cnn_band_plan(h, dtype_terms(h->d.dtype)) ? "cnn_band" : "layerwise";
+        h->last_plan = cnn_band_plan(h, dtype_terms(h->d.dtype)) ? "cnn_band" : cnn_in1_plan(h, dtype_terms(h->d.dtype)) ? "cnn_in1" : "layerwise";
         if ((rc = run_cnn(h, feat, B, T, logits, ws_act, s))) return rc;
     } else {
         return fail(KWS_EUNSUPPORTED, "handle was created with family KWS_MODEL_NONE (front end only)");
@@ -1067,6 +1110,14 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
             if (std::strcmp(field, "weight") == 0) {
                 if ((rc = need((size_t)L.g.Cout * L.g.Cin * L.g.kh * L.g.kw))) return rc;
                 if ((rc = upload_packed(L, src, h->lw_mode))) return rc;
+                if (idx == 0 && h->cnn_in1) {   // the same weights in conv_in1.hip's fragment order, for both of its tile groupings
+                    const int mhs[2] = {IN1_MH3, IN1_MH1};
+                    for (int v = 0; v < 2; ++v) {
+                        std::vector<unsigned short> pki;
+                        pack_conv_in1_weights(L.g.Cout, L.g.kh, mhs[v], src, L.x_scale, pki);
+                        if ((rc = L.apk_in1[v].upload(pki.data(), pki.size() * sizeof(unsigned short)))) return rc;
+                    }
+                }
                 if (idx == 1 && h->cnn_band_R > 0) {   // the same weights in conv_band.hip's fragment order
                     std::vector<unsigned short> pkb;
                     L.band_scale = weight_scale_pow2(src, (size_t)L.g.Cout * L.g.Cin * L.g.kh * L.g.kw);
@@ -1086,12 +1137,11 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
             if (std::strcmp(field, "weight") == 0) {
                 if ((rc = need((size_t)L.g.Cout * L.g.kw))) return rc;
                 if ((rc = upload_packed(L, src, h->lw_mode))) return rc;
-                if (li == 0 && h->cnn_band_R > 0) {
-                    // the band plan hands this Linear conv_1's output as (position, channel padded to 16) instead of the
-                    // reference's flatten order (channel, position): same weights, columns permuted, zeros for the padding
+                if (li == 0 && (h->cnn_band_R > 0 || h->cnn_cl1)) {
+                    // the channels-last plans hand this Linear the last conv's output as (position, channel padded to 16) instead
+                    // of the reference's flatten order (channel, position): same weights, columns permuted, zeros for the padding
                     ConvLayer& Lc = h->clin0_cl;
-                    const ConvGeom& g1 = h->cconv[1].g;
-                    const int npos = g1.Ho * g1.Wo, cp1 = h->cnn_cp[1], C1 = g1.Cout;
+                    const int C1 = h->cl_last[0], npos = h->cl_last[1], cp1 = h->cl_last[2];
                     std::vector<float> wcl((size_t)L.g.Cout * Lc.g.kw, 0.f);
                     for (int o = 0; o < L.g.Cout; ++o)
                         for (int c = 0; c < C1; ++c)

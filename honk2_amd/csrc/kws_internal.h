@@ -318,6 +318,25 @@ bool conv3x3_tile_supported(int C, int Cout, int Ws);
 void build_tile_conv_table(int H, int W, int ld_in, int ld_out, int ld_res, std::vector<int>& tab, int& cpc_in, int& cpc_out, int& cpc_res);
 void pack_conv3x3_tile_weights_f16(int C, const float* w /*C,C,3,3*/, float scale, std::vector<unsigned short>& dst);
 hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
+// First conv of the cnn-* models from an LDS image of the clip (conv_in1.hip): Cin == 1, kw == 8, no padding, fused MaxPool
+struct In1ConvParams {
+    const float* feat;     // (B, T, F) fp32 feature maps
+    void* out;             // channels-last (B, Hq, Wq, Cp): fp32, or fp16 when out_f16
+    const unsigned short* apk;   // pack_conv_in1_weights with the kernel's MH (IN1_MH3 for terms == 3, IN1_MH1 for terms == 1)
+    const float* bias;     // (Cout)
+    int B, T, F, Cout, Cp, mtiles;
+    int kh, sh, sw, ph, pw;   // kernel rows, strides, pooling window (1 x 1: none)
+    int Hq, Wq;            // pooled output map
+    int terms;             // 3: two-part fp16 operands (fp32-accurate); 1: plain fp16 products
+    float inv_scale;       // 2^-S of the weights
+    int relu, out_f16;
+    RangeGate rg;
+};
+constexpr int IN1_MH3 = 2, IN1_MH1 = 4;   // channel tiles a wave keeps in registers (three-term / single-term products)
+bool conv_in1_supported(const ConvGeom& g, int ph, int pw);
+size_t conv_in1_lds_bytes(int T, int F, int parts);
+void pack_conv_in1_weights(int Cout, int kh, int mh, const float* w, float scale, std::vector<unsigned short>& dst);
+hipError_t launch_conv_in1(const In1ConvParams& p, hipStream_t s);
 // LDS-staged band convolution for the second conv of the cnn-* models (conv_band.hip): stride 1, no padding, bias + ReLU
 struct BandConvParams {
     const void* in;        // channels-last (B, H, W, Cpi): fp32, or fp16 when terms == 1; channels >= Cin hold zeros

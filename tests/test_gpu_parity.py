@@ -153,9 +153,9 @@ def test_model_logits_match_reference(torch_cuda, fname):
     assert np.abs(got - want).max() < LOGIT_TOL, (tag, np.abs(got - want).max())
     assert (got.argmax(1) == want.argmax(1)).all()
     assert model.num_params() == int(z["num_params"])
-    # two-conv CNNs: conv_1 from LDS-staged bands (conv_band.hip); single-conv CNNs: the generic layer-wise kernels
+    # CNNs: conv_0 from an LDS image of the clip (conv_in1.hip), conv_1 from LDS-staged bands (conv_band.hip)
     assert model.plan_name() == ("res8_fused" if tag == "resnet__res8" else "resnet_tiled" if name == "ResNet" else
-                                 "cnn_band" if "conv_1" in cfg else "layerwise")
+                                 "cnn_band" if "conv_1" in cfg else "cnn_in1")
 
 
 @pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_cnn__cnn-trad-pool2.npz", "model_resnet__res8.npz"])

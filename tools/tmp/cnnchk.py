@@ -5,7 +5,6 @@ from conftest import load_golden_model
 from test_gpu_parity import _build
 for f in sorted(glob.glob("/root/repo/tests/golden/model_cnn__*.npz")):
     tag, name, cfg, sd, feats, z = load_golden_model(os.path.basename(f))
-    if "conv_1" not in cfg: continue
     x = torch.from_numpy(feats).cuda()
     want = z["logits"]
     for dt in ("f32", "fp16"):

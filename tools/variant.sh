@@ -8,7 +8,7 @@ make -s -j8 >/dev/null
 mkdir -p ../variants build/var_$name
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -fno-gpu-rdc $flags -x hip -c ${VARIANT_SRC:-$src} -o build/var_$name/$src.o
 objs=""
-for f in kws_api.cpp frontend.hip frontend_f16x3.hip res8_fused.hip res8_bf16x6.hip res8_f16x3.hip layerwise.hip layerwise_bf16x6.hip conv3x3_tile.hip conv_band.hip; do
+for f in kws_api.cpp frontend.hip frontend_f16x3.hip res8_fused.hip res8_bf16x6.hip res8_f16x3.hip layerwise.hip layerwise_bf16x6.hip conv3x3_tile.hip conv_band.hip conv_in1.hip; do
   if [ "$f" = "$src" ]; then objs="$objs build/var_$name/$f.o"; else objs="$objs build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o ../variants/lib_$name.so
