@@ -242,6 +242,37 @@ def test_res8_fused_equals_layerwise_and_oracle_on_a_larger_batch(torch_cuda, mo
     assert (a.argmax(1) == want.argmax(1))[clear].all() and clear.mean() > 0.9
 
 
+@pytest.mark.parametrize("fname,env,plan", [
+    ("model_cnn__cnn-tpool3.npz", {"KWS_CNN_IN1": "0"}, "cnn_band"),        # 3 x 3 MaxPool in the generic kernel's channels-last epilogue
+    ("model_cnn__cnn-trad-pool2.npz", {"KWS_CNN_IN1": "0"}, "cnn_band"),
+    ("model_cnn__cnn-tstride8.npz", {"KWS_CNN_IN1": "0"}, "cnn_band"),      # 126 -> 128 input channels per band cell
+    ("model_cnn__cnn-one-fstride8.npz", {"KWS_CNN_IN1": "0"}, "layerwise"),
+    ("model_cnn__cnn-tpool2.npz", {"KWS_CNN_BAND": "0"}, "layerwise"),
+])
+@pytest.mark.parametrize("dtype", ["f32", "fp16"])
+def test_cnn_plans_agree(torch_cuda, monkeypatch, fname, env, plan, dtype):
+    """The cnn-* models run conv_0 from an LDS image of the clip (conv_in1.hip), conv_1 from LDS-staged row bands (conv_band.hip)
+    and the first Linear on column-permuted weights.  KWS_CNN_IN1=0 keeps conv_0 in the generic kernel (channels-last epilogue),
+    KWS_CNN_BAND=0 keeps the whole model there: every combination must meet the same bar against the reference's logits."""
+    torch = torch_cuda
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    x = torch.from_numpy(feats).cuda()
+    want = z["logits"]
+    tol = LOGIT_TOL if dtype == "f32" else 5e-3 * max(1.0, float(np.abs(want).max()))
+    default = _build(torch, name, dict(cfg, dtype=dtype), sd)
+    got_default = default(x).cpu().numpy()
+    assert default.plan_name() == ("cnn_band" if "conv_1" in cfg else "cnn_in1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = _build(torch, name, dict(cfg, dtype=dtype), sd)
+    got = other(x).cpu().numpy()
+    assert other.plan_name() == plan
+    assert np.abs(got - want).max() < tol and np.abs(got_default - want).max() < tol, (tag, dtype)
+    if dtype == "f32":
+        assert np.abs(got - got_default).max() < 2e-5
+        assert (got.argmax(1) == want.argmax(1)).all() and (got_default.argmax(1) == want.argmax(1)).all()
+
+
 @pytest.mark.parametrize("impl", ["nchw", "fp32"])
 @pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_resnet__res26_narrow.npz", "model_cnn__cnn-tpool2.npz"])
 def test_alternative_layerwise_kernels_agree(torch_cuda, monkeypatch, fname, impl):
