@@ -143,13 +143,14 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
     constexpr bool S16 = TERMS == 1;                // 16-bit activation tensors
     constexpr int WP = F16 ? 2 : 3;                 // parts per weight fragment group (as packed on the host)
     constexpr int NP = t3_lds_parts(F16, TERMS);    // parts that take part in the products = parts per LDS cell
+    constexpr int CELL = NB * 16 * NP, PART = NB * 16;
     constexpr int GCELL = S16 ? NB * 16 : NB * 32;  // global cell: NB*8 channels x 2 or 4 B
     constexpr int STEPS = (9 * NB + 3) / 4;
     constexpr int TILE_P = t3_tile_positions(NP, NB);
     constexpr int JT = TILE_P / 64;                 // position tiles per wave (5 / 3)
     constexpr int NQ = S16 ? NB : NB * 2;           // 16-byte chunks per global cell (8 channels of 16 bits / 4 of fp32)
-    constexpr int NQQ = (NQ + 3) / 4;               // chunk quads per cell (a staging item = 16 cells x one quad)
-    constexpr int UNR = 7;                          // staging items of a wave in flight together
+    constexpr int NGRP = 256 / NQ;     // cells copied per pass
+    constexpr int UNR = S16 ? (NB == 6 ? (TILE_P <= 192 ? 7 : (TILE_P <= 320 ? 10 : 13)) : 4) : (NB == 6 ? 10 : 5);  // staging passes in flight together
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
 #ifdef T3_TIMING   // 100 MHz wall-clock stamps of this workgroup's phases (tools/t3_phases.py)
@@ -177,17 +178,8 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
     }
     const int P0 = tile_id * TILE_P;
     const int ncell = TILE_P + 2 * Ws + 2;
-    // LDS image: [part][8-channel block][cell] x 16 B -- block planes a multiple of 256 B apart, so the 16 consecutive cells of a
-    // position tile are conflict-free for ds_read_b128 (a service group = 8 lanes of one k-group + 8 of the next, section 2 of
-    // DESIGN.md; the cell-major image spent 53 % of its LDS cycles in bank conflicts) -- then one 16-byte zero slot per part
-    // (p.ncellp = ncell rounded up to 16 wherever two workgroups still fit a CU then -- t3_plane_cells; else ncell itself, and
-    // a quarter of the lanes of a service group collide two ways, as before)
-    const int ncellp = p.ncellp;
-    const int planeb = ncellp * 16;
-    const int partb = NB * planeb + 16;
-    const int zero_off = NB * planeb;               // part 0's zero slot (part pt: + pt * partb)
-    const int ktab_off = NP * partb;
-    const int border_off = ktab_off + 512;          // after the k-step table
+    const int zero_off = ncell * CELL;
+    const int border_off = zero_off + CELL + 512;   // after the zero cell and the k-step table
     const float inv_ws = 1.0f / (float)Ws, inv_hs = 1.0f / (float)Hs;
 
     // ---------------------------------------------------------------- this lane's output positions: one table entry each
@@ -204,17 +196,18 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
         int q;
         pb[j] = fdiv(P, p.cpc_in, inv_cpc, q);
         pe[j] = *reinterpret_cast<const i32x4*>(p.postab + 4 * q);
-        lbase[j] = (local + Ws + 1) * 16;
+        lbase[j] = (local + Ws + 1) * CELL;
     }
     T3_TS(8)
     T3_TS(1)
     // ---------------------------------------------------------------- stage cells [P0 - Ws - 1, P0 + TILE_P + Ws + 1)
     {
-        if (tid < NP) *reinterpret_cast<u32x4*>(lds + tid * partb + zero_off) = (u32x4){0u, 0u, 0u, 0u};
+        const int qd = tid % NQ, grp = tid / NQ;
+        if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + zero_off + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
         if (tid < 4 * (STEPS + 2)) {   // k-step table (see the k-loop): entry [s][g], two spare steps for the look-ahead
             const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
-            // (zero-weight padding blocks, tap >= 9, test bit 31 of the mask word, which is never set: they read the zero slot)
-            reinterpret_cast<int2_*>(lds + ktab_off)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * 16 + cblk * planeb - zero_off, tap < 9 ? tap : 31};
+            // (zero-weight padding blocks, tap >= 9, test bit 31 of the mask word, which is never set: they read the zero cell)
+            reinterpret_cast<int2_*>(lds + zero_off + CELL)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16 - zero_off, tap < 9 ? tap : 31};
         }
         // the border-bias table (16 border classes x NB*8 channels) goes to LDS: read from global memory in the epilogue, every one of
         // its loads waited -- vmcnt counts loads and stores alike -- for the previous block's output store as well (6.5 of 18 us per tile)
@@ -223,42 +216,39 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
             if (p.border) bv = *reinterpret_cast<const f32x4*>(p.border + 4 * tid);
             *reinterpret_cast<f32x4*>(lds + border_off + 16 * tid) = bv;
         }
-        // A staging item of a wave = 16 consecutive cells (lanes 0-15) x four consecutive 16-byte chunks of each (lane >> 4): 64
-        // contiguous bytes per cell for the vector-memory path, and every 16-lane group writes 16 consecutive cells of one block
-        // plane (conflict-free LDS stores).
-        {
+        if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
-            const int lc = lane & 15, lq = lane >> 4;
-            const int nit = ((ncell + 15) >> 4) * NQQ;
-            for (int i0 = w; i0 < nit; i0 += UNR * 4) {
+            for (int i0 = grp; i0 < ncell; i0 += UNR * NGRP) {
                 f32x4 v[UNR];
-                int dst[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const int it = min(i0 + u * 4, nit - 1);
-                    const int cg = it / NQQ, qq = it - cg * NQQ;
-                    const int i = cg * 16 + lc, ch = qq * 4 + lq;
-                    // Cells outside the tensor or in the padding of a sub-map are never tapped (tmask), so whatever is copied for
-                    // them is irrelevant: the address is clamped instead of tested.
-                    const int q = min(max(P0 - Ws - 1 + i, 0), p.total - 1);
-                    dst[u] = (i < ncell && ch < NQ) ? (S16 ? ch * planeb : (ch >> 1) * planeb + (ch & 1) * 8) + i * 16 : -1;
-                    v[u] = (p.debug & 2) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * GCELL + min(ch, NQ - 1) * 16);
+                    // Cells outside the tensor or in the padding of a sub-map are never tapped (tmask above), so whatever
+                    // is copied for them is irrelevant: the address is clamped instead of tested.
+                    const int q = min(max(P0 - Ws - 1 + i0 + u * NGRP, 0), p.total - 1);
+                    v[u] = (p.debug & 2) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * GCELL + qd * 16);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    if (i0 + u * 4 >= nit || dst[u] < 0) continue;
-                    if (S16) {           // the tensor already holds the operand type: eight channels, one 16-byte store
-                        *reinterpret_cast<f32x4*>(lds + dst[u]) = v[u];
-                    } else if (F16) {
-                        u32x2 pr[2];
-                        split4_f16(v[u], pr);
+                    const int i = i0 + u * NGRP;
+                    if (i < ncell) {
+                        if (S16) {           // the tensor already holds the operand type: eight channels, one 16-byte store
+                            *reinterpret_cast<f32x4*>(lds + i * CELL + qd * 16) = v[u];
+                        } else if (NP == 2 && !F16) {   // bf16x3: the two leading bf16 parts
+                            u32x2 pr[3];
+                            split4(v[u], pr);
 #pragma unroll
-                        for (int pt = 0; pt < 2; ++pt) *reinterpret_cast<u32x2*>(lds + pt * partb + dst[u]) = pr[pt];
-                    } else {             // bf16 parts: the leading NP of three
-                        u32x2 pr[3];
-                        split4(v[u], pr);
+                            for (int pt = 0; pt < 2; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                        } else if (F16) {
+                            u32x2 pr[2];
+                            split4_f16(v[u], pr);
 #pragma unroll
-                        for (int pt = 0; pt < NP; ++pt) *reinterpret_cast<u32x2*>(lds + pt * partb + dst[u]) = pr[pt];
+                            for (int pt = 0; pt < 2; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                        } else {
+                            u32x2 pr[3];
+                            split4(v[u], pr);
+#pragma unroll
+                            for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                        }
                     }
                 }
             }
@@ -313,7 +303,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
     // against 45 MFMAs: the k-loop was bound by its own address arithmetic (11 us per tile where the MFMAs need 5).
     // A tap that leaves the sub-map or the tensor (mask bit clear; always for the zero-weight padding blocks, tap >= 9) reads the
     // shared zero cell: address = zero_off + ((lbase + offz) & -(bit)).
-    const int2_* const ktab = reinterpret_cast<const int2_*>(lds + ktab_off) + g;
+    const int2_* const ktab = reinterpret_cast<const int2_*>(lds + zero_off + CELL) + g;
     auto b_addr = [&](int j, int2_ e) {
         const int m = __builtin_amdgcn_sbfe(tmask[j], e[1], 1);      // 0 or -1
         return zero_off + ((lbase[j] + e[0]) & m);
@@ -321,7 +311,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
 #define TLOADB(BR, ADDR)                                                                              \
     {                                                                                                 \
         const int ad_ = (ADDR);                                                                       \
-        _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) BR[pt] = *reinterpret_cast<const u32x4*>(lds + ad_ + pt * partb); \
+        _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) BR[pt] = *reinterpret_cast<const u32x4*>(lds + ad_ + pt * PART); \
     }
 #define TLOADA(AR, S)                                                                                 \
     {                                                                                                 \
@@ -423,16 +413,9 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
 }
 
 // one tile buffer (TILE_P + 2 Ws + 2 cells + the zero cell)
-static size_t t3_lds_bytes_for(int cp, int parts, int ncellp) {
-    return (size_t)parts * ((size_t)(cp / 8) * ncellp * 16 + 16) + 512 + 16 * cp * 4;   // image + zero slots + the k-step and border tables
+size_t conv3x3_tile_lds_bytes(int cp, int Ws, int parts) {
+    return (size_t)(t3_tile_positions(parts, cp / 8) + 2 * Ws + 3) * cp * 2 * parts + 512 + 16 * cp * 4;   // + the k-step and border tables
 }
-// cells per 8-channel block plane: the tile's cells rounded up to 16 (conflict-free planes) unless that costs the second workgroup of a CU
-int t3_plane_cells(int cp, int Ws, int parts) {
-    const int ncell = t3_tile_positions(parts, cp / 8) + 2 * Ws + 2, r16 = (ncell + 15) & ~15;
-    const size_t half_cu = 80 * 1024;
-    return (t3_lds_bytes_for(cp, parts, r16) <= half_cu || t3_lds_bytes_for(cp, parts, ncell) > half_cu) ? r16 : ncell;
-}
-size_t conv3x3_tile_lds_bytes(int cp, int Ws, int parts) { return t3_lds_bytes_for(cp, parts, t3_plane_cells(cp, Ws, parts)); }
 
 bool conv3x3_tile_supported(int C, int Cout, int Ws) {
     const int cp = (C + 7) / 8 * 8;
@@ -451,9 +434,7 @@ static hipError_t launch_t3k(const TileConvParams& p, hipStream_t s) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    TileConvParams q = p;
-    q.ncellp = t3_plane_cells(NB * 8, p.Ws, t3_lds_parts(F16, TERMS));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, q);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 

@@ -309,7 +309,6 @@ struct TileConvParams {
     // instructions per position) is one 16-byte load.
     const int* postab;
     int cpc_in, cpc_out, cpc_res;
-    int ncellp;            // cells per LDS block plane (set by the launcher: t3_plane_cells)
     unsigned long long* dbg_ts;   // KWS_T3_TIMING (with a -DT3_TIMING build): 8 stamps per workgroup for the first 8192 workgroups, or nullptr
     int debug;             // KWS_T3_DEBUG, timing experiments only (results are wrong when set): 1 skip the k-loop, 2 skip the
                            // staging loads, 4 skip the output stores, 8 skip the residual read, 16 skip the k-loop's weight-fragment loads
