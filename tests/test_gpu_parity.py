@@ -273,6 +273,51 @@ def test_cnn_plans_agree(torch_cuda, monkeypatch, fname, env, plan, dtype):
         assert (got.argmax(1) == want.argmax(1)).all() and (got_default.argmax(1) == want.argmax(1)).all()
 
 
+_ODD_CNNS = {
+    # conv_0 with 16 kernel rows, stride (1, 2), 2 x 1 pool; 40 -> 48 channels through a 4 x 3 conv_1; straight to the labels
+    "in1_band": ({"time": 81, "frequency": 48, "dropout_prob": 0.5, "n_labels": 7,
+                  "conv_0": {"out_channels": 40, "kernel_size": [16, 8], "stride": [1, 2]}, "pool_0": {"kernel_size": [2, 1]},
+                  "conv_1": {"out_channels": 48, "kernel_size": [4, 3], "stride": [1, 1]}, "pool_1": {"kernel_size": [1, 1]}}, "cnn_band"),
+    # twelve kernel rows (three k-steps: not a shape conv_in1.hip is built for): conv_0 stays in the generic kernel and writes
+    # channels-last cells from its epilogue, conv_1 on bands; 20 channels in 32-channel cells
+    "generic_band": ({"time": 64, "frequency": 40, "dropout_prob": 0.5, "n_labels": 5,
+                      "conv_0": {"out_channels": 20, "kernel_size": [12, 8], "stride": [1, 1]}, "pool_0": {"kernel_size": [2, 2]},
+                      "conv_1": {"out_channels": 40, "kernel_size": [5, 5], "stride": [1, 1]}, "pool_1": {"kernel_size": [1, 1]},
+                      "lin_0": {"out_features": 24}}, "cnn_band"),
+    # strided conv_1: no band plan, nothing channels-last
+    "strided_conv1": ({"time": 101, "frequency": 40, "dropout_prob": 0.5, "n_labels": 12,
+                       "conv_0": {"out_channels": 32, "kernel_size": [20, 8], "stride": [1, 1]}, "pool_0": {"kernel_size": [2, 2]},
+                       "conv_1": {"out_channels": 32, "kernel_size": [6, 4], "stride": [2, 1]}, "pool_1": {"kernel_size": [1, 1]}}, "layerwise"),
+    # a 42-wide map (not a multiple of four) keeps the single-conv model off the LDS-image kernel
+    "odd_width": ({"time": 50, "frequency": 42, "dropout_prob": 0.5, "n_labels": 4,
+                   "conv_0": {"out_channels": 30, "kernel_size": [24, 8], "stride": [1, 2]}, "pool_0": {"kernel_size": [1, 3]},
+                   "lin_0": {"out_features": 16}, "dnn_0": {"out_features": 32}}, "layerwise"),
+    # 21 kernel rows padded to 24 (zero weights under uninitialised-looking rows), 3 x 3 pool, 130 channels in nine tiles
+    "in1_wide": ({"time": 70, "frequency": 40, "dropout_prob": 0.5, "n_labels": 3,
+                  "conv_0": {"out_channels": 130, "kernel_size": [21, 8], "stride": [2, 1]}, "pool_0": {"kernel_size": [3, 3]},
+                  "lin_0": {"out_features": 32}}, "cnn_in1"),
+}
+
+
+@pytest.mark.parametrize("case", sorted(_ODD_CNNS))
+@pytest.mark.parametrize("dtype", ["f32", "fp16"])
+def test_cnn_geometries_beyond_the_shipped_configs(torch_cuda, case, dtype):
+    """The cnn-* kernels (conv_in1.hip, conv_band.hip, the channels-last epilogue and the column-permuted Linear) on geometries
+    none of the shipped configs has -- other map sizes, strides, pooling windows, channel counts that need padding -- each against
+    the fp32 CPU oracle (reference model/cnn.py:79-107), and the plan each of them must take."""
+    torch = torch_cuda
+    from oracle import models, weights
+    cfg, plan = _ODD_CNNS[case]
+    sd = weights.make_state_dict("CNN", cfg, seed=5)
+    feats = weights.make_features(37, seed=6, time=cfg["time"], freq=cfg["frequency"])
+    model = _build(torch, "CNN", dict(cfg, dtype=dtype), sd)
+    got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert model.plan_name() == plan
+    want = models.forward_torch("CNN", cfg, sd, feats).numpy()
+    tol = LOGIT_TOL if dtype == "f32" else 5e-3 * max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() < tol, (case, dtype, np.abs(got - want).max())
+
+
 @pytest.mark.parametrize("impl", ["nchw", "fp32"])
 @pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_resnet__res26_narrow.npz", "model_cnn__cnn-tpool2.npz"])
 def test_alternative_layerwise_kernels_agree(torch_cuda, monkeypatch, fname, impl):
