@@ -179,7 +179,7 @@ def test_reduced_precision_mode_bf16x3(torch_cuda, fname):
 
 
 @pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_cnn__cnn-trad-pool2.npz", "model_resnet__res8.npz",
-                                   "model_resnet__res26_narrow.npz"])
+                                   "model_resnet__res26_narrow.npz", "model_hey_snips__res26.npz", "model_resnet__res8_narrow.npz"])
 def test_plain_bf16_mode(torch_cuda, fname):
     """`dtype: "bf16"` (BASELINE configs[2]: res15 bf16): operands rounded to bf16 at the matrix cores, fp32 accumulation.
     Tolerance 2e-2 at |logit| ~ 1 as SURVEY.md Appendix C prescribes; argmax compared only where the reference's
@@ -200,7 +200,8 @@ def test_plain_bf16_mode(torch_cuda, fname):
     assert np.abs(x3 - want).max() < err         # the three-term mode sits between bf16 and the default
 
 
-@pytest.mark.parametrize("fname", ["model_cnn__cnn-trad-pool2.npz", "model_resnet__res15.npz", "model_resnet__res8.npz"])
+@pytest.mark.parametrize("fname", ["model_cnn__cnn-trad-pool2.npz", "model_resnet__res15.npz", "model_resnet__res8.npz",
+                                   "model_hey_snips__res26.npz", "model_resnet__res15_narrow.npz", "model_cnn__cnn-one-fstride4.npz"])
 def test_plain_fp16_mode(torch_cuda, fname):
     """`dtype: "fp16"` (BASELINE configs[4]: cnn-trad-pool2 fp16): operands rounded to fp16 at the matrix cores (weights carry a
     power-of-two scale), fp32 accumulation.  Tolerance 5e-3 at |logit| ~ 1 as SURVEY.md Appendix C prescribes for fp16,
@@ -415,7 +416,8 @@ def test_fused_res8_fp16_range_guard(torch_cuda):
     assert np.abs(got - want).max() < 2e-6 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("case", ["res15", "res26_narrow", "generic30", "cnn-trad-pool2", "cnn-tpool2-fp16"])
+@pytest.mark.parametrize("case", ["res15", "res26_narrow", "generic30", "cnn-trad-pool2", "cnn-tpool2-fp16", "res15-fp16",
+                                  "cnn-one-fpool3"])
 def test_layerwise_fp16_range_guard(torch_cuda, case):
     """The layer-wise plans' default operands are two-part fp16 splits, which cannot hold |x| > 65 504, while the reference is
     fp32 throughout (model/resnet.py:48-55, model/cnn.py:79-107).  Every kernel that stores an activation notes its largest
@@ -426,15 +428,17 @@ def test_layerwise_fp16_range_guard(torch_cuda, case):
     torch = torch_cuda
     from oracle import models, weights
     dtype = "f32"
-    if case == "res15":
+    if case.startswith("res15"):   # "res15-fp16": fp16 TENSORS between the layers; the recomputed chunk runs on fp32 tensors
         name, cfg = "ResNet", {"n_feature_maps": 45, "n_layers": 13, "use_dilation": True, "n_labels": 12}
+        dtype = "fp16" if case.endswith("fp16") else "f32"
     elif case == "res26_narrow":
         name, cfg = "ResNet", {"n_feature_maps": 19, "n_layers": 24, "use_dilation": False, "pool": [2, 2], "n_labels": 12}
     elif case == "generic30":
         name, cfg = "ResNet", {"n_feature_maps": 30, "n_layers": 6, "use_dilation": True, "n_labels": 12}
     else:
         name = "CNN"
-        _, _, cfg, _, _, _ = load_golden_model("model_cnn__cnn-trad-pool2.npz" if case == "cnn-trad-pool2" else "model_cnn__cnn-tpool2.npz")
+        _, _, cfg, _, _, _ = load_golden_model({"cnn-trad-pool2": "model_cnn__cnn-trad-pool2.npz", "cnn-tpool2-fp16": "model_cnn__cnn-tpool2.npz",
+                                                "cnn-one-fpool3": "model_cnn__cnn-one-fpool3.npz"}[case])
         dtype = "fp16" if case.endswith("fp16") else "f32"
     sd = weights.make_state_dict(name, cfg, seed=5)
     n_clean, n = 1024, 1100
