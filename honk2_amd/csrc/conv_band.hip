@@ -74,7 +74,14 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w & 1, wn = w >> 1;
     const int g = lane >> 4, pcol = lane & 15;
-    const int band = (int)blockIdx.x % p.nbands, b = (int)blockIdx.x / p.nbands;
+    // the bands of a clip share kh - 1 of their input rows: blocks that share an XCD (blockIdx mod 8) take a contiguous run of
+    // (clip, band) units, so the rows a neighbour already fetched are L2 hits (bijective for any grid size)
+    int unit = (int)blockIdx.x;
+    {
+        const int nwg = (int)gridDim.x, xcd = unit & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        unit = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (unit >> 3);
+    }
+    const int band = unit % p.nbands, b = unit / p.nbands;
     const int r0 = band * p.R;                       // first output row = first input row of the band
     const int rows_out = min(p.R, p.Ho - r0);
     const int rows_in = p.R + p.kh - 1;
