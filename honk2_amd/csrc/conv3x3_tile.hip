@@ -4,27 +4,35 @@
 // even i) -> BatchNorm(affine=False)).
 //
 // The generic layer-wise kernels (layerwise*.hip) read every input value nine times (once per tap) from L2 and split
-// it into bf16 parts each time; they are bound by that traffic / VALU work, not by the matrix pipe.  Here a workgroup
-// copies the cells its 192 output positions need into LDS ONCE, splitting each fp32 value into its three bf16 parts
-// on the way in, and all nine taps are served from LDS as ready-made B fragments, as in the fused res8 kernel.
+// it into 16-bit parts each time; they are bound by that traffic / VALU work, not by the matrix pipe.  Here a workgroup
+// copies the cells its output positions need into LDS ONCE, splitting each fp32 value into its parts on the way in, and
+// all nine taps are served from LDS as ready-made B fragments, as in the fused res8 kernel.
 //
-//   * Tensors are "CL": [cell][channel padded to 8] fp32 (C = 45 -> 192 B per cell), cells in "layout(d)":
+//   * Tensors are "CL": [cell][channel padded to 8] (C = 45 -> 48 channels), cells in "layout(d)":
 //         [clip][y mod d][x mod d][y / d][x / d]
+//     fp32 (192 B per cell) in the fp32-accurate and bf16x3 modes; the 16-bit operand type itself (96 B) with single-term
+//     products (`bf16` / `fp16` dtypes: staging is then a plain copy).
 //     A conv with dilation d only couples positions with equal (y mod d, x mod d), so in layout(d) it is a DENSE 3x3 conv
 //     on d*d independent sub-maps of ceil(H/d) x ceil(W/d) cells: the halo of a tile is one row + one cell on each side
 //     whatever the dilation.  A layer writes the layout its consumer wants straight from its epilogue and reads the
 //     residual in the layout it was written in, so there is no reshuffling pass.  Sub-maps are padded to a common size;
 //     taps that leave the sub-map, land in its padding or outside the tensor read a shared zero cell (per-position tap
-//     mask), so what staging copies for such cells never matters.
-//   * One workgroup = 192 consecutive positions of the flattened layout (12 position tiles, 3 per wave) plus a halo of
-//     Ws + 1 cells on each side; LDS cell = [part 0..2][channel] bf16 (288 B), <= 79 KB, two workgroups per CU, so one
-//     stages / stores while the other's waves keep the matrix pipe busy.  All of a thread's staging loads are in flight
-//     together; the residual is requested before the k-loop.
-//   * K order (tap, 8-channel block), 4 blocks per v_mfma_f32_16x16x32_bf16, six bf16 x bf16 terms per fp32-accurate
-//     product (res8_bf16x6.hip); weights pre-split on the host (pack_conv_weights_bf16x6) and read per wave from L2, one
-//     k-step ahead; B fragments are three ds_read_b128 per position tile, one tile ahead.
-//   * Epilogue: border bias (the previous BatchNorm's shift over the in-bounds taps, layerwise.hip), ReLU, residual,
-//     16-byte stores (4 channels) into layout(d_next).
+//     mask), so what staging copies for such cells never matters.  Everything that depends on a position only (tap mask,
+//     border class, validity, its cell in the output and residual layouts) comes from a per-layer table of one clip's cells
+//     built on the host (build_tile_conv_table).
+//   * One workgroup = 320 consecutive positions of the flattened layout (20 position tiles, 5 per wave; 192 = 3 per wave
+//     with three-part bf16 cells or <= 24 channels) plus a halo of Ws + 1 cells on each side; LDS cell = [part][channel]
+//     (two fp16 parts: 192 B; one part: 96 B; three bf16 parts: 288 B), <= 80 KB, two or three workgroups per CU.
+//     Workgroups that share an XCD take a contiguous run of tiles (halo re-reads hit that L2).  All of a thread's
+//     staging loads are in flight together; the residual is requested before the k-loop.
+//   * K order (tap, 8-channel block), 4 blocks per v_mfma_f32_16x16x32_{f16,bf16}; three fp16 x fp16 terms per
+//     fp32-accurate product by default (res8_f16x3.hip), six bf16 terms in the range-free form, three / one in the reduced
+//     dtypes; weights pre-split on the host and read per wave from L2, one k-step ahead; B fragments are one ds_read_b128
+//     per part and position tile, one tile ahead; the (tap, offset) of a k-step comes from a 512-byte LDS table.
+//   * Epilogue: border bias (the previous BatchNorm's shift over the in-bounds taps) from a table in LDS, ReLU, residual,
+//     16-byte (fp32) / 8-byte (16-bit) channels-last stores into layout(d_next); the largest stored magnitude feeds the fp16
+//     range guard.
+// conv0_cl_kernel (conv_0 + ReLU [+ AvgPool] straight into a CL tensor) and mean_linear_cl_kernel (the tail) live here too.
 #include "kws_internal.h"
 
 namespace kws {
