@@ -111,6 +111,49 @@ def cpu_baseline(torch, wav_sample, sd, budget_s=12.0):
     return rec, want
 
 
+def secondary_configs(torch, device):
+    """BASELINE configs[2] (res15, `bf16`, B = 4096) and configs[4] (cnn-trad-pool2, `fp16`, B = 8192), features -> logits in their
+    own dtype on synthetic feature maps with the models' own initialisation: reported next to the headline, never mixed into it.
+    TFLOP/s are algorithmic (2 x MAC of the conv / linear stack), the roof is the dense 16-bit MFMA peak (single-term products)."""
+    from honk2_amd.utils import find_cls
+    res15 = {"n_feature_maps": 45, "n_layers": 13, "use_dilation": True, "n_labels": 12}
+    trad = {"time": 101, "frequency": 40, "dropout_prob": 0.5, "n_labels": 12,
+            "conv_0": {"out_channels": 64, "kernel_size": [20, 8], "stride": [1, 1]}, "pool_0": {"kernel_size": [2, 2]},
+            "conv_1": {"out_channels": 64, "kernel_size": [10, 4], "stride": [1, 1]}, "pool_1": {"kernel_size": [1, 1]}}
+    out = []
+    for tag, name, cfg, dtype, batch, mflop in (("configs[2] res15 bf16", "ResNet", res15, "bf16", 4096, 1917.63),
+                                                ("configs[4] cnn-trad-pool2 fp16", "CNN", trad, "fp16", 8192, 192.37)):
+        torch.manual_seed(7)
+        model = find_cls(f"model.{name}")(dict(cfg, dtype=dtype))
+        g = torch.Generator().manual_seed(1)
+        sd = model.state_dict()
+        for k, v in sd.items():
+            if k.endswith("running_mean"):
+                sd[k] = 0.3 + 0.2 * torch.randn(v.shape, generator=g)
+            elif k.endswith("running_var"):
+                sd[k] = 0.25 + 0.5 * torch.rand(v.shape, generator=g)
+        model.load_state_dict(sd)
+        model = model.to(device).eval()
+        x = torch.randn(batch, 101, 40, device=device) * 2.5 + 0.65
+        for _ in range(2):
+            model(x)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 5
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            y = model(x)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / reps
+        out.append({"config": tag, "plan": model.plan_name(), "dtype": dtype, "batch": batch, "ms": ms, "clips_per_s": batch / ms * 1e3,
+                    "TFLOPs_alg": batch / ms * 1e3 * mflop * 1e6 / 1e12, "frac_of_2516_TFLOPs": batch / ms * 1e3 * mflop * 1e6 / 1e12 / 2516.0,
+                    "finite": bool(torch.isfinite(y).all().item()), "what": "features -> logits, own initialisation, synthetic feature maps"})
+        del model, x, y
+        torch.cuda.empty_cache()
+    return out
+
+
 def parity_record(got, want, tol=1e-3):
     """GPU logits vs the oracle's on the same clips: the north-star bar (|diff| <= 1e-3, argmax equal).  With |diff| <= e on
     every logit the argmax can only differ where the oracle's own top-1 / top-2 margin is below 2 e, so a mismatch on a
@@ -137,6 +180,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="GLOBAL batch (clips per step over all GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] records (N = 1 only)")
     args = ap.parse_args()
 
     import torch
@@ -263,6 +307,11 @@ def main():
             out["cpu_baseline"], want = cpu_baseline(torch, wav[:16384], sd)
             out["parity"] = parity_record(logits[:len(want)].cpu().numpy(), want)
             failed = not out["parity"]["pass"]
+        if world == 1 and not args.no_secondary:
+            try:
+                out["secondary"] = secondary_configs(torch, device)
+            except Exception as exc:                   # never let an extra record take the headline line down
+                out["secondary"] = {"error": repr(exc)}
         dump = os.environ.get("KWS_BENCH_DUMP")        # tests: the (gathered) logits of the last step, for comparison across N
         if dump:
             import numpy as np

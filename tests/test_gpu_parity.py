@@ -813,7 +813,7 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(torch_cuda, tmp_path):
     assert "cpu_baseline" not in line2 and line2["roofline"]["launches"] == 2
     env1 = dict(os.environ, KWS_BENCH_DUMP=str(tmp_path / "n1.npy"))
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                          "--batch", "2048", "--no-cpu-baseline"], env=env1, capture_output=True, text=True, timeout=600, cwd=root)
+                          "--batch", "2048", "--no-cpu-baseline", "--no-secondary"], env=env1, capture_output=True, text=True, timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
     line1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert line1["n_gpus"] == 1 and line1["config"]["clips_per_gpu"] == 2048
