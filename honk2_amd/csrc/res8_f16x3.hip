@@ -81,8 +81,6 @@ constexpr int BNT_WORDS = R8_LAYERS * 96;
 constexpr int NEXT_OFF = RED_OFF + (4 * 48 + 48 + BNT_WORDS) * 4;   // one word: the clip this workgroup takes next
 constexpr int POS_OFF = NEXT_OFF + 16;                // the position table (336 x 2 B)
 constexpr int X_LDS_BYTES = POS_OFF + 21 * 16 * 2;
-constexpr int KSTEPS = R8X_KSTEPS;                    // 14
-constexpr int A_STEP = 3 * 2 * 64;                    // u32x4 per k-step: [channel tile][part][lane]
 
 __device__ __forceinline__ float relu1(float x) {
     const int b = __builtin_bit_cast(int, x);
@@ -103,35 +101,28 @@ __device__ __forceinline__ unsigned resid2(unsigned h, float a, float b) {
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
     return l;
 }
-// split 4 consecutive channels into two fp16 parts and store them at byte address `addr` (+ part * 96)
-__device__ __forceinline__ void store_split(char* lds, int addr, f32x4 v) {
+// split 4 consecutive channels into two fp16 parts and store them at LDS address `addr` (+ PART_B for part 2)
+typedef u32x2 __attribute__((address_space(3))) * lds_u32x2_ptr;
+__device__ __forceinline__ void store_split(int addr, f32x4 v) {
     u32x2 h, m;
     h[0] = pack2(v[0], v[1]);
     h[1] = pack2(v[2], v[3]);
     m[0] = resid2(h[0], v[0], v[1]);
     m[1] = resid2(h[1], v[2], v[3]);
-    *reinterpret_cast<u32x2*>(lds + addr) = h;
-    *reinterpret_cast<u32x2*>(lds + addr + PART_B) = m;
+    *reinterpret_cast<lds_u32x2_ptr>((unsigned)addr) = h;
+    *reinterpret_cast<lds_u32x2_ptr>((unsigned)(addr + PART_B)) = m;
 }
-// byte offset (from a lane's cell in plane 0) of channels 16 m + 4 g .. + 3: channel block 2 m + (g >> 1), its upper or lower half
-__device__ __forceinline__ int st_off(int m, int g) { return (2 * m + (g >> 1)) * PLANE_B + 8 * (g & 1); }
-
-#define MF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
-// three-term product, small terms first
-#define MF6(A2, B_, C_)       \
-    if (TERMS >= 3) {         \
-        MF(A2[1], B_[0], C_); \
-        MF(A2[0], B_[1], C_); \
-    }                         \
-    MF(A2[0], B_[0], C_);
 
 struct XCtx {
     char* lds;
     float* red;
     float* mvec;
     const float* bnt;
-    int tid, lane, w, g, pcol, mx;
-    int qb[6];   // byte address of this lane's cell (part 0, channel block 0) in each of the wave's 6 position tiles
+    int tid, lane, w, g, pcol;
+    int cm[3];   // channel tile behind the wave's slot m (wave-uniform): slot 0 is the tile the wave also owns on position tile 20
+    int qa[6];   // byte address of this lane's k-slot base in each of the wave's 6 position tiles (see "K order" below)
+    int es[3];   // store address of slot m's four channels, relative to qa[j]
+    int dB, dC, dD;   // what kinds B, C, D add to qa[j]
     int padmask; // bit j: this lane of tile j is a pad lane (a clone of another lane: stored again, but counted once)
     bool xvalid;
 };
@@ -171,162 +162,187 @@ __device__ __forceinline__ int range_shift(float mx) {   // 0 for mx <= 2^14 (an
 }
 
 struct AFrags {
-    u32x4 a[3][2];   // [channel tile][part]; the extra position tile uses a[mx] (mx is wave-uniform)
+    u32x4 a[3][2];   // [slot][part]
 };
 struct BFrag {
-    u32x4 p[2];      // the two fp16 parts of one position tile's B fragment
+    u32x4 p[2];      // the two fragments of one position tile and k-step (regular steps: the two fp16 parts of the same cells)
 };
 
-// byte offset (from the lane's cell in plane 0) of this lane's k-slot at k-step s: block bi = 4 s + g -> tap = bi / 6, channel block bi % 6
-__device__ __forceinline__ int step_boff(int s, int g) {
-    int bi = 4 * s + g;
-    bi = bi < 54 ? bi : 53;   // blocks 54, 55 are zero-weight padding: re-read a valid block
-    const int tap = bi / 6, cblk = bi - 6 * tap, ty = tap / 3, tx = tap - 3 * ty;
-    return cblk * PLANE_B + ((ty - 1) * R8_RS + (tx - 1)) * 16;
+// ---- K order.  K = 9 taps x 6 blocks of 8 input channels = 54 blocks, four per k-step (one per lane group g).  The blocks
+// are dealt to the steps so that a lane's LDS address is  qa[j] + (per-kind lane constant) + (compile-time immediate):
+//   kind A, steps 0..8   taps (3 i, 3 i + 1) x channel-block pair q:  g -> block 2 q + (g & 1) of tap 3 i + (g >> 1)
+//   kind B, steps 9..11  taps (2, 5) x pair q:                        g -> block 2 q + (g & 1) of tap 2 + 3 (g >> 1)
+//   kind C, step 12      tap 8, blocks 0..3:                          g -> block g
+//   kind D, step 13      tap 8, blocks 4, 5 -- half a step, so its a1 b1 and a1 b2 terms share ONE MFMA: groups 0, 1 read
+//                        part 1 of the cells, groups 2, 3 part 2 of the same two blocks, against a fragment that carries a1
+//                        twice; a2 b1 is a second MFMA on a regular part-1 read (2 MFMAs per tile instead of 3).
+// qa[j] already holds kind A's lane constant (g & 1) PLANE_B + (g >> 1) 16 and a bias of -QBIAS (tap 0 reaches back 15
+// cells; ds_read offsets are unsigned); kinds B, C, D add one per-lane register each (dB, dC, dD).  With the step loop
+// fully unrolled the k-loop carries no address arithmetic beyond those adds (4.5 of 13.5 steps): 9 vector instructions per
+// k-step before (two integer divisions per step pair), 2 now.
+constexpr int QBIAS = (R8_RS + 1) * 16;
+constexpr int tap_off(int t) { return ((t / 3 - 1) * R8_RS + (t % 3 - 1)) * 16; }
+constexpr int step_kind(int s) { return s < 9 ? 0 : (s < 12 ? 1 : (s == 12 ? 2 : 3)); }
+constexpr int step_imm(int s) {
+    return s < 9    ? 2 * (s % 3) * PLANE_B + tap_off(3 * (s / 3)) + QBIAS
+           : s < 12 ? 2 * (s - 9) * PLANE_B + tap_off(2) + QBIAS
+           : s == 12 ? tap_off(8) + QBIAS
+                     : 4 * PLANE_B + tap_off(8) + QBIAS;
 }
-__device__ __forceinline__ void load_a(AFrags& f, const u32x4* A, int s, int mx) {
-    const u32x4* As = A + (size_t)s * A_STEP;
+static_assert(step_imm(8) + PART_B < 65536 && step_imm(0) >= 0, "ds_read offsets are 16 bits, unsigned");
+constexpr int KSTEPS = R8X_KSTEPS;                    // 14
+constexpr int A_FRAG_B = 64 * 16;                     // one A fragment: 1 KB
+constexpr int A_STEP_B = 3 * 2 * A_FRAG_B;            // a k-step's fragments: [channel tile][part][lane] x 16 B
+constexpr int A_LAYER_B = R8H_ASTEPS * A_STEP_B;
+
+// (c.qa[] are full 32-bit LDS addresses: one VGPR + a 16-bit immediate per ds_read_b128, nothing for the compiler to re-derive)
+typedef const u32x4 __attribute__((address_space(3))) * lds_u32x4_ptr;
+__device__ __forceinline__ u32x4 lds_read16(int addr) { return *reinterpret_cast<lds_u32x4_ptr>((unsigned)addr); }
+__device__ __forceinline__ void load_b(BFrag& b, const int (&qa)[6], int dB, int dC, int dD, int s, int j) {
+    const int k = step_kind(s), imm = step_imm(s);
+    if (k == 3) {
+        b.p[0] = lds_read16((qa[j] + dD) + imm);   // (part 1 | part 2) of blocks 4, 5
+        b.p[1] = lds_read16(qa[j] + imm);          // part 1 (groups 2, 3 meet zero weights)
+    } else {
+        const int base = k == 0 ? qa[j] : qa[j] + (k == 1 ? dB : dC);
+        b.p[0] = lds_read16(base + imm);
+        b.p[1] = lds_read16(base + imm + PART_B);
+    }
+}
+// the six fragments of k-step `sidx` (0 .. 6 * 14 - 1 over the layers): scalar base + per-slot scalar offset + lane offset
+__device__ __forceinline__ void load_a(AFrags& f, __amdgpu_buffer_rsrc_t rs, int voff, int sbase, const int (&om)[3]) {
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) f.a[m][pt] = As[(m * 2 + pt) * 64];
-    (void)mx;
-}
-// fragment 0 from byte address a0, fragment 1 from a1 (a regular k-step: the two parts of one cell, a1 = a0 + PART_B)
-__device__ __forceinline__ void load_b(BFrag& b, const char* lds, int a0, int a1) {
-    b.p[0] = *reinterpret_cast<const u32x4*>(lds + a0);
-    b.p[1] = *reinterpret_cast<const u32x4*>(lds + a1);
+        for (int pt = 0; pt < 2; ++pt)
+            f.a[m][pt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + pt * A_FRAG_B, sbase + om[m], 0));
 }
 
-// One k-step: 16 tiles x 3 terms.  B fragments are fetched ONE position tile ahead (two ds_read_b128 in flight -- the LDS
-// counter is 4 bits, a whole k-step's reads cannot be outstanding); (OA_NEXT, OB_NEXT) address tile 0 of the NEXT k-step.
-// A fragments of the next k-step were requested by the caller before this step's MFMAs.  MFS(m, B, C) issues the step's
-// MFMAs of channel tile m.
-#define X_STEP(MFS, OA, OB, OA_NEXT, OB_NEXT)                                         \
-    {                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 6; ++j) {                               \
-            BFrag& bcur = (j & 1) ? bb1 : bb0;                                        \
-            BFrag& bnxt = (j & 1) ? bb0 : bb1;                                        \
-            if (R8H_ABLATE && (p.debug & 4)) {                                        \
-            } else if (j < 5) load_b(bnxt, c.lds, c.qb[j + 1] + (OA), c.qb[j + 1] + (OB));   \
-            else load_b(bnxt, c.lds, c.qb[0] + (OA_NEXT), c.qb[0] + (OB_NEXT));       \
-            __builtin_amdgcn_sched_barrier(0);                                        \
-            if (j < 5) {                                                              \
-                _Pragma("unroll") for (int m = 0; m < 3; ++m) { MFS(m, bcur.p, acc[j][m]) } \
-            } else {                                                                  \
-                if (c.mx == 0) { MFS(0, bcur.p, accx) }                               \
-                else if (c.mx == 1) { MFS(1, bcur.p, accx) }                          \
-                else if (c.w == 2) { MFS(2, bcur.p, accx) }   /* wave 3 owns no extra tile */ \
-            }                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                        \
-        }                                                                             \
+#define MF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
+
+// the MFMAs of one (k-step, position tile, slot): three-term product, small terms first
+template <int TERMS>
+__device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag& b, f32x4& acc) {
+    if (step_kind(s) == 3) {
+        if (TERMS >= 3) MF(a[1], b.p[1], acc);   // a2 b1
+        MF(a[0], b.p[0], acc);                   // a1 b1 + a1 b2
+    } else {
+        if (TERMS >= 3) {
+            MF(a[1], b.p[0], acc);
+            MF(a[0], b.p[1], acc);
+        }
+        MF(a[0], b.p[0], acc);
     }
+}
 
 // A/B knobs of this file (defaults = what measured best):
-//   R8H_PRIO      wave priority inside the k-loops (s_setprio; the matrix stream of one workgroup against the vector-heavy
-//                 phases of the other workgroup on the same SIMD)
-//   R8H_PREFETCH  the first weight fragments of layer i + 1 are requested before layer i's epilogue and barriers
+//   R8H_PRIO      wave priority inside the k-loops (s_setprio)
 #ifndef R8H_PRIO
 #define R8H_PRIO 0
-#endif
-#ifndef R8H_PREFETCH
-#define R8H_PREFETCH 1
 #endif
 #ifndef R8H_ABLATE      // 1: KWS_R8_DEBUG bits 4 / 8 drop the k-loops' LDS operand reads / weight loads (timing experiments; results are wrong)
 #define R8H_ABLATE 0
 #endif
 
-template <int TERMS, bool EVEN, bool LAST>
-__device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int layer, int clip, f32x4 (&prev)[5][3],
-                                        f32x4& prevx, int& shift, AFrags& fa0) {
-    const int g = c.g, mx = c.mx;
+// One conv_i + epilogue (i = layer + 1).  `fa0` arrives holding k-step 0's weight fragments (requested before the previous
+// epilogue and its barriers) and leaves holding the next layer's.
+template <int TERMS>
+__device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __amdgpu_buffer_rsrc_t ars, int avoff, const int (&om)[3],
+                                        const int layer, const int clip, f32x4 (&prev)[5][3], f32x4& prevx, int& shift,
+                                        AFrags (&fa)[2]) {
+    const bool even = layer & 1, last = layer == R8_LAYERS - 1;   // reference layer i = layer + 1: residual on even i
+    const int g = c.g;
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 acc[5][3], accx;
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-#pragma unroll
-        for (int m = 0; m < 3; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    accx = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const u32x4* A = reinterpret_cast<const u32x4*>(p.apk2) + (size_t)layer * R8H_ASTEPS * A_STEP + c.lane;
-    AFrags fa1;
-    if (R8H_ABLATE) fa1 = fa0;
-    BFrag bb0, bb1;   // ping-pong over position tiles; 6 tiles per step keeps the parity aligned across steps
-    if (R8H_ABLATE) bb1.p[0] = bb1.p[1] = (u32x4){0x3c003c00u, 0x38003800u, 0x3a003a00u, 0x34003400u};
-    if (!R8H_PREFETCH) load_a(fa0, A, 0, mx);   // otherwise requested by the previous layer (or by the clip prologue)
+    BFrag bb[2];   // ping-pong over position tiles; 6 tiles per step keeps the parity aligned across steps
+    if (R8H_ABLATE) bb[0].p[0] = bb[0].p[1] = bb[1].p[0] = bb[1].p[1] = (u32x4){0x3c003c00u, 0x38003800u, 0x3a003a00u, 0x34003400u};
     if (R8H_PRIO) __builtin_amdgcn_s_setprio(R8H_PRIO);
-    load_b(bb0, c.lds, c.qb[0] + step_boff(0, g), c.qb[0] + step_boff(0, g) + PART_B);
-#define MFS0(M, B, C) MF6(fa0.a[M], B, C)
-#define MFS1(M, B, C) MF6(fa1.a[M], B, C)
-#define X_PAIR(S)                                                                                                  \
-    {                                                                                                              \
-        const int o0 = step_boff((S), g), o1 = step_boff((S) + 1, g),                                              \
-                  o2 = step_boff((S) + 2 < KSTEPS ? (S) + 2 : KSTEPS - 1, g);                                      \
-        if (!(R8H_ABLATE && (p.debug & 8))) load_a(fa1, A, (S) + 1, mx);                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        X_STEP(MFS0, o0, o0 + PART_B, o1, o1 + PART_B)                                                             \
-        if (!(R8H_ABLATE && (p.debug & 8))) load_a(fa0, A, (S) + 2 < KSTEPS ? (S) + 2 : KSTEPS - 1, mx); /* last one is a harmless re-read */ \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        X_STEP(MFS1, o1, o1 + PART_B, o2, o2 + PART_B)                                                             \
-    }
+    const int sb = layer * A_LAYER_B;
+    // per-lane offsets are re-materialised per layer from opaque copies: left alone, LICM hoists every sum built from them
+    // (store addresses, k-slot bases, table addresses: ~40 registers) out of the layer loop and the allocator spills them
+    int dB = c.dB, dC = c.dC, dD = c.dD, es[3] = {c.es[0], c.es[1], c.es[2]};
+    asm volatile("" : "+v"(dB), "+v"(dC), "+v"(dD), "+v"(es[0]), "+v"(es[1]), "+v"(es[2]), "+v"(avoff));
     if (!(p.debug & 2)) {
-        if (TERMS >= 3) {
-            // The last k-step holds only blocks 52 and 53 (lane groups 0, 1): its a1 b1 and a1 b2 terms share ONE MFMA --
-            // groups 0, 1 read part 1 of the cells, groups 2, 3 part 2 of the same two blocks, against a fragment that
-            // carries a1 twice (k-step slot 14 of the packed weights) -- so the step costs 2 MFMAs per tile, not 3.
-#pragma unroll 1   // unrolled, the scheduler hoists weight loads of later steps and spills at 256 registers
-            for (int s = 0; s < KSTEPS - 2; s += 2) X_PAIR(s)
-            const int o12 = step_boff(KSTEPS - 2, g), o13 = step_boff(KSTEPS - 1, g);
-            const int om = step_boff(KSTEPS - 1, g & 1) + (g >> 1) * PART_B;      // merged fragment: block 52 + (g & 1), part g >> 1
-            load_a(fa1, A, KSTEPS - 1, mx);
+        if (!(R8H_ABLATE && (p.debug & 4))) load_b(bb[0], c.qa, dB, dC, dD, 0, 0);
+        // B fragments are fetched ONE position tile ahead (two ds_read_b128 in flight -- the LDS counter is 4 bits, a whole
+        // k-step's reads cannot be outstanding); A fragments one k-step ahead, the last step requests the next layer's first.
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const AFrags& fc = fa[s & 1];
+            if (!(R8H_ABLATE && (p.debug & 8))) {
+                if (s + 1 < KSTEPS) load_a(fa[(s + 1) & 1], ars, avoff, sb + (s + 1) * A_STEP_B, om);
+                else load_a(fa[(s + 1) & 1], ars, avoff, last ? sb : sb + A_LAYER_B, om);   // (last layer: a harmless re-read)
+            }
             __builtin_amdgcn_sched_barrier(0);
-            X_STEP(MFS0, o12, o12 + PART_B, om, o13)
-            load_a(fa0, A, KSTEPS, mx);                                            // fa0.a[m][0] = (a1 | a1)
-            __builtin_amdgcn_sched_barrier(0);
-#define MFSL(M, B, C)            \
-    MF(fa1.a[M][1], B[1], C);    \
-    MF(fa0.a[M][0], B[0], C);
-            X_STEP(MFSL, om, o13, om, o13)                                         // (the last prefetch is a harmless re-read)
-#undef MFSL
-        } else {
-#pragma unroll 1
-            for (int s = 0; s < KSTEPS; s += 2) X_PAIR(s)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const BFrag& bcur = bb[j & 1];
+                if (R8H_ABLATE && (p.debug & 4)) {
+                } else if (j < 5) load_b(bb[(j + 1) & 1], c.qa, dB, dC, dD, s, j + 1);
+                else if (s + 1 < KSTEPS) load_b(bb[(j + 1) & 1], c.qa, dB, dC, dD, s + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j < 5) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        if (s == 0) acc[j][m] = zero;
+                        mf_tile<TERMS>(s, fc.a[m], bcur, acc[j][m]);
+                    }
+                } else if (c.w < 3) {   // wave 3 owns no extra tile
+                    if (s == 0) accx = zero;
+                    mf_tile<TERMS>(s, fc.a[0], bcur, accx);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[j][m] = zero;
+        accx = zero;
     }
-#undef X_PAIR
-#undef MFS0
-#undef MFS1
     if (R8H_PRIO) __builtin_amdgcn_s_setprio(0);
-    if (R8H_PREFETCH && !LAST) {   // next layer's first fragments: in flight across this layer's epilogue and barriers
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(fa0, A + (size_t)R8H_ASTEPS * A_STEP, 0, mx);
-        __builtin_amdgcn_sched_barrier(0);
-    }
 
     // ---- epilogue in fp32: ReLU, residual (reference: even i), BatchNorm as one FMA.  The accumulators carry the layer's
-    //      weight scale 2^S; 2^-S rides on the residual FMA (even layers) or is already folded into the BatchNorm scale of
-    //      the table (odd layers).
+    //      weight scale 2^S; 2^-S rides on the residual FMA (even i) or is already folded into the BatchNorm scale of
+    //      the table (odd i).
     const float* bt = c.bnt + layer * 96 + 4 * g;
     const float up = shift > 0 ? ldexpf(1.f, shift) : 1.f;   // undo the range guard of the map this layer read (uniform)
     const float inv = p.inv_scale[layer] * up;
     float amax = 0.f;
-    // (odd layers: the power of two that undoes the range guard of the input map rides on the BatchNorm scale -- twelve
+    // (odd i: the power of two that undoes the range guard of the input map rides on the BatchNorm scale -- twelve
     // multiplies by 1.0 in the common case instead of a select per value)
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        f32x4 sc = *reinterpret_cast<const f32x4*>(bt + 16 * m);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(bt + 48 + 16 * m);
-        if (!EVEN) sc *= up;
+        f32x4 sc = *reinterpret_cast<const f32x4*>(bt + 16 * c.cm[m]);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(bt + 48 + 16 * c.cm[m]);
+        if (!even) sc *= up;
+        if (even) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaf(relu1(acc[j][m][r]), inv, prev[j][m][r]);
+                    prev[j][m][r] = v;
+                    acc[j][m][r] = fmaf(v, sc[r], sh[r]);
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[j][m][r] = fmaf(relu1(acc[j][m][r]), sc[r], sh[r]);
+        }
+        if (m == 0) {   // the extra tile holds slot 0's channels
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = relu1(acc[j][m][r]);
-                if (EVEN) {
-                    v = fmaf(v, inv, prev[j][m][r]);
-                    prev[j][m][r] = v;
+                float v = relu1(accx[r]);
+                if (even) {
+                    v = fmaf(v, inv, prevx[r]);
+                    prevx[r] = v;
                 }
-                acc[j][m][r] = fmaf(v, sc[r], sh[r]);
+                accx[r] = fmaf(v, sc[r], sh[r]);
             }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j)
@@ -335,29 +351,15 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
             amax = fmaxf(fmaxf(amax, fabsf(acc[j][m][0])), fabsf(acc[j][m][1]));
             amax = fmaxf(fmaxf(amax, fabsf(acc[j][m][2])), fabsf(acc[j][m][3]));
         }
-    {
-        f32x4 sc = *reinterpret_cast<const f32x4*>(bt + 16 * mx);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(bt + 48 + 16 * mx);
-        if (!EVEN) sc *= up;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = relu1(accx[r]);
-            if (EVEN) {
-                v = fmaf(v, inv, prevx[r]);
-                prevx[r] = v;
-            }
-            accx[r] = fmaf(v, sc[r], sh[r]);
-        }
-        if (c.xvalid) {
-            amax = fmaxf(fmaxf(amax, fabsf(accx[0])), fabsf(accx[1]));
-            amax = fmaxf(fmaxf(amax, fabsf(accx[2])), fabsf(accx[3]));
-        }
+    if (c.xvalid) {
+        amax = fmaxf(fmaxf(amax, fabsf(accx[0])), fabsf(accx[1]));
+        amax = fmaxf(fmaxf(amax, fabsf(accx[2])), fabsf(accx[3]));
     }
     unsigned* const ggrp = reinterpret_cast<unsigned*>(c.red) + 4 * ((layer + 1) & 1);   // the reduction buffer is idle until the tail
-    if (!LAST) guard_push(ggrp, c.w, c.lane, amax);
+    if (!last) guard_push(ggrp, c.w, c.lane, amax);
 
     __syncthreads();  // every wave has finished reading this layer's input map
-    if (!LAST) {
+    if (!last) {
         shift = __builtin_amdgcn_readfirstlane(range_shift(guard_read(ggrp)));   // uniform
         if (shift > 0) {   // never taken for trained models: keep it a (wave-uniform) branch, not selects on every value
             asm volatile("; range guard: scale the map down" ::: "memory");
@@ -371,8 +373,8 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
-            for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + st_off(m, g), acc[j][m]);
-        if (c.xvalid) store_split(c.lds, c.qb[5] + st_off(mx, g), accx);
+            for (int m = 0; m < 3; ++m) store_split(c.qa[j] + es[m], acc[j][m]);
+        if (c.xvalid) store_split(c.qa[5] + es[0], accx);
         __syncthreads();
     } else {
 #pragma unroll
@@ -386,7 +388,7 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
                 v += __shfl_xor(v, 4);
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 1);
-                if (c.pcol == 0) c.red[c.w * 48 + 16 * m + 4 * g + r] = v;
+                if (c.pcol == 0) c.red[c.w * 48 + 16 * c.cm[m] + 4 * g + r] = v;
             }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -395,7 +397,7 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, int
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 1);
-            if (c.pcol == 0 && c.w < 3) c.red[c.w * 48 + 16 * mx + 4 * g + r] += v;
+            if (c.pcol == 0 && c.w < 3) c.red[c.w * 48 + 16 * c.cm[0] + 4 * g + r] += v;
         }
         __syncthreads();
         if (c.tid < 48)
@@ -416,10 +418,8 @@ size_t res8h_lds_bytes() { return (size_t)X_LDS_BYTES; }
 // Two workgroups (two clips) per CU: 77 KB of LDS and <= 256 registers each.  While one is in an epilogue, in conv_0 or
 // waiting for its features, the other's waves use the matrix pipe -- the overlap a single workgroup with one wave per SIMD
 // cannot have.  Measured (KWS_R8_WGS_PER_CU=1|2 with this very kernel): 21.9 -> 16.9 ms per 65 536 clips; the one-wave-
-// per-SIMD, 502-register build of the same code took 18.0 ms.  The accumulator file is not what limits the overlap (a lone
-// wave issues an MFMA every 17 clocks with VGPR or AGPR accumulators: tools/mfma_acc_probe.cpp); the two workgroups of a CU
-// simply do not run at the same speed (84 against 106 us per clip: the arbiters favour the older waves), hence the clip
-// queue below, and the kernel as a whole is clock-limited.  A start-up stagger of the second
+// per-SIMD, 502-register build of the same code took 18.0 ms.  The two workgroups of a CU do not run at the same speed (84
+// against 106 us per clip: the arbiters favour the older waves), hence the clip queue below.  A start-up stagger of the second
 // workgroup changes nothing (v8: second workgroup identified per physical CU -- HW_ID / XCC_ID arrival counters -- and
 // delays of 30 / 60 / 90 k ticks: 13.62 - 13.76 ms, noise).
 // phase timestamps for tools/r8_phases.py: build with -DR8H_TIMING (they overwrite the consumed feature rows)
@@ -443,8 +443,17 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
     c.bnt = bnt;
 
     c.w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    c.mx = c.w < 2 ? c.w : 2;
-    const int w = c.w, mx = c.mx;
+    const int w = c.w;
+    // slot m of wave w holds channel tile (w + m) mod 3: slot 0 is then the tile the wave owns on position tile 20 (waves
+    // 0..2), and no instruction of the k-loop depends on which wave runs it
+    int om[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        c.cm[m] = (w + m) % 3;
+        om[m] = c.cm[m] * 2 * A_FRAG_B;
+    }
+    const __amdgpu_buffer_rsrc_t ars =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.apk2), 0, R8_LAYERS * A_LAYER_B, 0x00020000);
 
     for (int i = threadIdx.x; i < BNT_WORDS; i += 256) bnt[i] = p.bn_tab[i];
     unsigned short* const pos_tab = reinterpret_cast<unsigned short*>(ldsb + POS_OFF);
@@ -474,6 +483,8 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         c.pcol = c.lane & 15;
         const int g = c.g, pcol = c.pcol, lane = c.lane;
         c.padmask = 0;
+        const int ga = (g & 1) * PLANE_B + (g >> 1) * 16 - QBIAS;
+        const int lds0 = (int)(unsigned)reinterpret_cast<uintptr_t>(ldsb);   // low word of the flat address = the LDS address
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int nt = j < 5 ? 5 * w + j : 20;
@@ -481,9 +492,14 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
             const int nn = e & 0x7fff;
             const int y = nn / W8_W;
             const int x = nn - y * W8_W;
-            c.qb[j] = ((y + 1) * R8_RS + x + 1) * 16;
+            c.qa[j] = ((y + 1) * R8_RS + x + 1) * 16 + ga + lds0;
             c.padmask |= (e >> 15) << j;
         }
+        c.dB = (g >> 1) * (R8_RS - 1) * 16;               // second tap of the pair: one row down instead of one cell right
+        c.dC = (g >> 1) * (2 * PLANE_B - 16);             // four channel blocks of one tap
+        c.dD = (g >> 1) * (PART_B - 16);                  // groups 2, 3: part 2 of the same cell
+#pragma unroll
+        for (int m = 0; m < 3; ++m) c.es[m] = (2 * c.cm[m] + (g >> 1)) * PLANE_B + 8 * (g & 1) - ga;
         c.xvalid = w < 3 && !((c.padmask >> 5) & 1);
 
         // ---- stage the (101, 40) feature map as fp32 with a zero top row / left column, inside the idle map region
@@ -552,11 +568,11 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 if (TERMS >= 3) {
-                    a0[m][0] = A0[(6 + m) * 64];      // the K-packed fragments follow the two-part ones
+                    a0[m][0] = A0[(6 + c.cm[m]) * 64];      // the K-packed fragments follow the two-part ones
                     a0[m][1] = a0[m][0];
                 } else {
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) a0[m][pt] = A0[(m * 2 + pt) * 64];
+                    for (int pt = 0; pt < 2; ++pt) a0[m][pt] = A0[(c.cm[m] * 2 + pt) * 64];
                 }
             }
             const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -632,14 +648,12 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                         f32x4 cx = zero;
                         if (TERMS >= 3) {
                             C0_FRAGK(lbw[5], oy, ox, bh)
-                            if (mx == 0) { MF(a0[0][0], bh, cx); }
-                            else if (mx == 1) { MF(a0[1][0], bh, cx); }
-                            else { MF(a0[2][0], bh, cx); }
+                            MF(a0[0][0], bh, cx);
                         } else {
                             C0_FRAG(lbw[5], oy, ox, bh, bl)
-                            if (mx == 0) { MF(a0[0][1], bh, cx); MF(a0[0][0], bl, cx); MF(a0[0][0], bh, cx); }
-                            else if (mx == 1) { MF(a0[1][1], bh, cx); MF(a0[1][0], bl, cx); MF(a0[1][0], bh, cx); }
-                            else { MF(a0[2][1], bh, cx); MF(a0[2][0], bl, cx); MF(a0[2][0], bh, cx); }
+                            MF(a0[0][1], bh, cx);
+                            MF(a0[0][0], bl, cx);
+                            MF(a0[0][0], bh, cx);
                         }
                         sx += relu4(cx);
                     }
@@ -653,8 +667,9 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         // every wave is done with the staged features: turn the region back into a map -- zero halo, then the pooled conv_0
         // output in its interior
         int shift;   // range guard of the map the next layer reads
-        AFrags fa_next;
-        if (R8H_PREFETCH) load_a(fa_next, reinterpret_cast<const u32x4*>(p.apk2) + c.lane, 0, mx);   // conv_1's first weight fragments
+        const int avoff = lane * 16;
+        AFrags fa[2];
+        load_a(fa[0], ars, avoff, 0, om);   // conv_1's first weight fragments
         {
             float amax = 0.f;
 #pragma unroll
@@ -681,27 +696,27 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
-                for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + st_off(m, g), prev[j][m] * down);
-            if (c.xvalid) store_split(c.lds, c.qb[5] + st_off(mx, g), prevx * down);
+                for (int m = 0; m < 3; ++m) store_split(c.qa[j] + c.es[m], prev[j][m] * down);
+            if (c.xvalid) store_split(c.qa[5] + c.es[0], prevx * down);
         } else {
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
-                for (int m = 0; m < 3; ++m) store_split(c.lds, c.qb[j] + st_off(m, g), prev[j][m]);
-            if (c.xvalid) store_split(c.lds, c.qb[5] + st_off(mx, g), prevx);
+                for (int m = 0; m < 3; ++m) store_split(c.qa[j] + c.es[m], prev[j][m]);
+            if (c.xvalid) store_split(c.qa[5] + c.es[0], prevx);
         }
         __syncthreads();
 
         R8H_TS(3)
-        x_layer<TERMS, false, false>(p, c, 0, clip, prev, prevx, shift, fa_next);
-        R8H_TS(4)
-        x_layer<TERMS, true, false>(p, c, 1, clip, prev, prevx, shift, fa_next);
-        R8H_TS(5)
-        x_layer<TERMS, false, false>(p, c, 2, clip, prev, prevx, shift, fa_next);
-        x_layer<TERMS, true, false>(p, c, 3, clip, prev, prevx, shift, fa_next);
-        x_layer<TERMS, false, false>(p, c, 4, clip, prev, prevx, shift, fa_next);
-        R8H_TS(6)
-        x_layer<TERMS, true, true>(p, c, 5, clip, prev, prevx, shift, fa_next);
+#pragma unroll 1   // one copy of the layer's code: the six inlined copies of round 2 made the kernel 66 KB, more than the instruction cache
+        for (int layer = 0; layer < R8_LAYERS; ++layer) {
+            x_layer<TERMS>(p, c, ars, avoff, om, layer, clip, prev, prevx, shift, fa);
+#ifdef R8H_TIMING
+            if (layer == 0) { R8H_TS(4) }
+            else if (layer == 1) { R8H_TS(5) }
+            else if (layer == 4) { R8H_TS(6) }
+#endif
+        }
         R8H_TS(7)
 #ifdef R8H_TIMING
         if ((threadIdx.x & 63) == 0) {      // the clip's features are dead: park the timestamps there (tools/r8_phases.py)
@@ -768,37 +783,43 @@ void pack_res8h_conv0(const float* wt, float scale, unsigned short* dst) {
         }
 }
 
-// conv_i weight (45,45,3,3) times `scale` -> [k-step 14][channel tile 3][part 2][lane 64][8 fp16]:
-//   cout = 16 m + (lane & 15); block bi = 4 s + (lane >> 4): tap = bi / 6, input channels 8 (bi % 6) .. +7; bi >= 54: zeros
+// conv_i weight (45,45,3,3) times `scale` -> [k-step 14][channel tile 3][part 2][lane 64][8 fp16] in the kernel's K order
+// (kinds A - D above): cout = 16 m + (lane & 15), lane group g = lane >> 4 holds 8 input channels of one tap.  The last
+// step's part-1 fragment carries a1 of blocks 4, 5 of tap 8 on groups 0, 1 AND on groups 2, 3 (it meets part 1 | part 2 of
+// the activations in one MFMA), its part-2 fragment a2 on groups 0, 1 and zeros on groups 2, 3.
 void pack_res8h_layer(const float* wt, float scale, unsigned short* dst) {
-    auto weight = [&](int co, int bi, int j, bool low) -> unsigned short {
+    auto weight = [&](int co, int tap, int cblk, int j, bool low) -> unsigned short {
         float v = 0.f;
-        if (bi < 54 && co < R8_C) {
-            const int tap = bi / 6, ci = 8 * (bi % 6) + j;
-            if (ci < R8_C) v = wt[((size_t)co * R8_C + ci) * 9 + tap] * scale;
-        }
+        const int ci = 8 * cblk + j;
+        if (co < R8_C && ci < R8_C) v = wt[((size_t)co * R8_C + ci) * 9 + tap] * scale;
         const unsigned short h = f16_rne_host(v);
         return low ? f16_rne_host(v - f16_to_f_host(h)) : h;
     };
     for (int s = 0; s < KSTEPS; ++s)
         for (int m = 0; m < 3; ++m)
             for (int lane = 0; lane < 64; ++lane) {
-                const int co = 16 * m + (lane & 15), bi = 4 * s + (lane >> 4);
+                const int co = 16 * m + (lane & 15), g = lane >> 4;
+                int tap, cblk;
+                bool zero_low = false;
+                if (s < 9) {
+                    tap = 3 * (s / 3) + (g >> 1);
+                    cblk = 2 * (s % 3) + (g & 1);
+                } else if (s < 12) {
+                    tap = 2 + 3 * (g >> 1);
+                    cblk = 2 * (s - 9) + (g & 1);
+                } else if (s == 12) {
+                    tap = 8;
+                    cblk = g;
+                } else {
+                    tap = 8;
+                    cblk = 4 + (g & 1);
+                    zero_low = g >= 2;
+                }
                 for (int j = 0; j < 8; ++j) {
-                    dst[((((size_t)s * 3 + m) * 2 + 0) * 64 + lane) * 8 + j] = weight(co, bi, j, false);
-                    dst[((((size_t)s * 3 + m) * 2 + 1) * 64 + lane) * 8 + j] = weight(co, bi, j, true);
+                    dst[((((size_t)s * 3 + m) * 2 + 0) * 64 + lane) * 8 + j] = weight(co, tap, cblk, j, false);
+                    dst[((((size_t)s * 3 + m) * 2 + 1) * 64 + lane) * 8 + j] = zero_low ? 0 : weight(co, tap, cblk, j, true);
                 }
             }
-    // slot 14: part 1 of the last k-step's two real blocks (52, 53) on lane groups 0, 1 AND on groups 2, 3 -- the merged
-    // fragment that meets (part 1 | part 2) of the activations in one MFMA; its second fragment is unused (zero)
-    for (int m = 0; m < 3; ++m)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int co = 16 * m + (lane & 15), bi = 4 * (KSTEPS - 1) + ((lane >> 4) & 1);
-            for (int j = 0; j < 8; ++j) {
-                dst[((((size_t)KSTEPS * 3 + m) * 2 + 0) * 64 + lane) * 8 + j] = weight(co, bi, j, false);
-                dst[((((size_t)KSTEPS * 3 + m) * 2 + 1) * 64 + lane) * 8 + j] = 0;
-            }
-        }
 }
 
 }  // namespace kws

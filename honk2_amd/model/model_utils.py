@@ -11,6 +11,7 @@ same weights as the reference.
 """
 import ctypes as C
 import math
+import threading
 from abc import ABC
 
 import torch
@@ -54,8 +55,12 @@ class BatchNormStats(nn.Module):
 class BaseModel(ABC, nn.Module):
     def __init__(self):
         super().__init__()
-        self._engine = None
-        self._engine_key = None
+        # One engine (kws_handle + weights + workspace) per GPU the module's tensors have been seen on.  The dict and its
+        # lock are shared -- by reference -- between the shallow per-device replicas ``nn.DataParallel`` makes (the
+        # reference's multi-GPU mechanism, ``run/test.py:69-70``): each replica thread finds or creates the engine of its
+        # own device and never touches (let alone destroys) another replica's handle.
+        self._engines = {}
+        self._engines_lock = threading.Lock()
 
     def num_params(self):
         return sum(p.numel() for p in self.parameters())
@@ -71,21 +76,22 @@ class BaseModel(ABC, nn.Module):
         return tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
 
     def engine(self):
-        """The kws_handle for this model with the current weights loaded (re-uploaded when they change)."""
-        device = next(self.parameters()).device          # the engine lives where the model's tensors live
-        if self._engine is not None and device.type == "cuda" and self._engine.device != (
-                device if device.index is not None else torch.device("cuda", torch.cuda.current_device())):
-            self._engine.close()                          # the model was moved to another GPU after its first use
-            self._engine = None
-        if self._engine is None:
-            self._engine = _lib.Engine(self._make_desc(), device if device.type == "cuda" else None)
-            self._engine_key = None
+        """The kws_handle of the device this module's tensors live on, with the current weights loaded (re-uploaded when
+        they change).  Engines of other devices stay alive until the module is garbage-collected."""
+        device = next(self.parameters()).device           # (parameters still on the host: the current GPU computes)
+        if not torch.cuda.is_available():
+            raise RuntimeError("honk2_amd: no ROCm device visible to PyTorch; the HIP path is mandatory (no CPU fallback)")
+        index = device.index if device.type == "cuda" and device.index is not None else torch.cuda.current_device()
         key = self._weights_key()
-        if key != self._engine_key:
-            for name, tensor in self.state_dict().items():
-                self._engine.load_tensor(name, tensor)
-            self._engine_key = key
-        return self._engine
+        with self._engines_lock:
+            slot = self._engines.get(index)
+            if slot is None:
+                slot = self._engines[index] = [_lib.Engine(self._make_desc(), torch.device("cuda", index)), None]
+            if slot[1] != key:
+                for name, tensor in self.state_dict().items():
+                    slot[0].load_tensor(name, tensor)
+                slot[1] = key
+            return slot[0]
 
     def _require_eval(self):
         if self.training:

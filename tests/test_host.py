@@ -199,3 +199,43 @@ def test_streaming_dataset_matches_the_reference_class(tag, case):
     assert len(stream) == (n - 1) * shift + window
     w5, _ = ds[5]
     assert np.array_equal(stream[5 * shift:5 * shift + window], w5)
+
+
+def test_data_parallel_replicas_get_one_engine_per_device_and_never_close_each_others(monkeypatch):
+    """nn.DataParallel replicas are shallow __dict__ copies (reference multi-GPU mechanism, run/test.py:69-70): the replica
+    on cuda:1 must build its own engine and leave the one the cuda:0 replica is using alone."""
+    from honk2_amd.model import model_utils
+
+    class FakeEngine:
+        created, closed = [], []
+
+        def __init__(self, desc, device):
+            self.device = torch.device(device)
+            self.loaded = 0
+            FakeEngine.created.append(self)
+
+        def load_tensor(self, name, tensor):
+            self.loaded += 1
+
+        def close(self):
+            FakeEngine.closed.append(self)
+
+    current = {"index": 0}
+    monkeypatch.setattr(model_utils._lib, "Engine", FakeEngine)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: current["index"])
+    cfg = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 12}
+    model = find_cls("model.ResNet")(dict(cfg)).eval()
+    replica = model._replicate_for_data_parallel()       # what torch.nn.parallel.replicate does per device
+    replica._parameters, replica._buffers, replica._modules = model._parameters, model._buffers, model._modules
+    e0 = model.engine()
+    current["index"] = 1
+    e1 = replica.engine()
+    current["index"] = 0
+    assert e0 is not e1 and (e0.device.index, e1.device.index) == (0, 1)
+    assert model.engine() is e0 and FakeEngine.closed == [] and len(FakeEngine.created) == 2
+    n = e0.loaded
+    assert model.engine() is e0 and e0.loaded == n          # unchanged weights are not uploaded again
+    with torch.no_grad():
+        next(model.parameters()).add_(1.0)                  # a new version -> re-upload, on that device's engine only
+    assert model.engine() is e0 and e0.loaded == 2 * n and e1.loaded == n
