@@ -240,8 +240,32 @@ __device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag&
 #ifndef R8H_PRIO
 #define R8H_PRIO 0
 #endif
+#ifndef R8H_EPRIO   // wave priority OUTSIDE the k-loops (epilogues, conv_0, staging, tail)
+#define R8H_EPRIO 0
+#endif
+#ifndef R8H_BDEPTH   // position tiles of look-ahead of the k-loop's LDS reads
+#define R8H_BDEPTH 1
+#endif
 #ifndef R8H_ABLATE      // 1: KWS_R8_DEBUG bits 4 / 8 drop the k-loops' LDS operand reads / weight loads (timing experiments; results are wrong)
 #define R8H_ABLATE 0
+#endif
+
+// phase timestamps for tools/r8_phases.py: build with -DR8H_TIMING (they overwrite the consumed feature rows)
+#ifdef R8H_TIMING
+#define R8H_TS_DECL unsigned long long ts[16] = {}, rt0 = __builtin_amdgcn_s_memrealtime();
+#define R8H_TS(i) ts[i] = __builtin_readcyclecounter();
+#else
+#define R8H_TS_DECL
+#define R8H_TS(i)
+#endif
+#ifdef R8H_TIMING
+#define R8H_LTS(i) if (layer == 2) ts[i] = __builtin_readcyclecounter();
+#define R8H_TSARG , unsigned long long (&ts)[16]
+#define R8H_TSPASS , ts
+#else
+#define R8H_LTS(i)
+#define R8H_TSARG
+#define R8H_TSPASS
 #endif
 
 // One conv_i + epilogue (i = layer + 1).  `fa0` arrives holding k-step 0's weight fragments (requested before the previous
@@ -249,23 +273,29 @@ __device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag&
 template <int TERMS>
 __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __amdgpu_buffer_rsrc_t ars, int avoff, const int (&om)[3],
                                         const int layer, const int clip, f32x4 (&prev)[5][3], f32x4& prevx, int& shift,
-                                        AFrags (&fa)[2]) {
+                                        AFrags (&fa)[2] R8H_TSARG) {
     const bool even = layer & 1, last = layer == R8_LAYERS - 1;   // reference layer i = layer + 1: residual on even i
     const int g = c.g;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 acc[5][3], accx;
-    BFrag bb[2];   // ping-pong over position tiles; 6 tiles per step keeps the parity aligned across steps
-    if (R8H_ABLATE) bb[0].p[0] = bb[0].p[1] = bb[1].p[0] = bb[1].p[1] = (u32x4){0x3c003c00u, 0x38003800u, 0x3a003a00u, 0x34003400u};
-    if (R8H_PRIO) __builtin_amdgcn_s_setprio(R8H_PRIO);
+    constexpr int NB = R8H_BDEPTH + 1;
+    BFrag bb[NB];   // ring over the (k-step, position tile) sequence
+    if (R8H_ABLATE)
+        for (int i = 0; i < NB; ++i) bb[i].p[0] = bb[i].p[1] = (u32x4){0x3c003c00u, 0x38003800u, 0x3a003a00u, 0x34003400u};
+    if (R8H_PRIO | R8H_EPRIO) __builtin_amdgcn_s_setprio(R8H_PRIO);
+    R8H_LTS(8)
     const int sb = layer * A_LAYER_B;
     // per-lane offsets are re-materialised per layer from opaque copies: left alone, LICM hoists every sum built from them
     // (store addresses, k-slot bases, table addresses: ~40 registers) out of the layer loop and the allocator spills them
     int dB = c.dB, dC = c.dC, dD = c.dD, es[3] = {c.es[0], c.es[1], c.es[2]};
     asm volatile("" : "+v"(dB), "+v"(dC), "+v"(dD), "+v"(es[0]), "+v"(es[1]), "+v"(es[2]), "+v"(avoff));
     if (!(p.debug & 2)) {
-        if (!(R8H_ABLATE && (p.debug & 4))) load_b(bb[0], c.qa, dB, dC, dD, 0, 0);
-        // B fragments are fetched ONE position tile ahead (two ds_read_b128 in flight -- the LDS counter is 4 bits, a whole
-        // k-step's reads cannot be outstanding); A fragments one k-step ahead, the last step requests the next layer's first.
+        // B fragments are fetched R8H_BDEPTH position tiles ahead (2 ds_read_b128 per tile; the LDS counter is 4 bits, a
+        // whole k-step's reads cannot be outstanding); A fragments one k-step ahead, the last step requests the next layer's
+        // first.
+        if (!(R8H_ABLATE && (p.debug & 4)))
+#pragma unroll
+            for (int t = 0; t < R8H_BDEPTH; ++t) load_b(bb[t % NB], c.qa, dB, dC, dD, t / 6, t % 6);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const AFrags& fc = fa[s & 1];
@@ -276,10 +306,9 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __a
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const BFrag& bcur = bb[j & 1];
-                if (R8H_ABLATE && (p.debug & 4)) {
-                } else if (j < 5) load_b(bb[(j + 1) & 1], c.qa, dB, dC, dD, s, j + 1);
-                else if (s + 1 < KSTEPS) load_b(bb[(j + 1) & 1], c.qa, dB, dC, dD, s + 1, 0);
+                const int t = 6 * s + j, tn = t + R8H_BDEPTH;
+                const BFrag& bcur = bb[t % NB];
+                if (!(R8H_ABLATE && (p.debug & 4)) && tn < 6 * KSTEPS) load_b(bb[tn % NB], c.qa, dB, dC, dD, tn / 6, tn % 6);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 5) {
 #pragma unroll
@@ -293,6 +322,8 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __a
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (s == 0) { R8H_LTS(9) }
+            if (s == 6) { R8H_LTS(10) }
         }
     } else {
 #pragma unroll
@@ -301,7 +332,8 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __a
             for (int m = 0; m < 3; ++m) acc[j][m] = zero;
         accx = zero;
     }
-    if (R8H_PRIO) __builtin_amdgcn_s_setprio(0);
+    if (R8H_PRIO | R8H_EPRIO) __builtin_amdgcn_s_setprio(R8H_EPRIO);
+    R8H_LTS(11)
 
     // ---- epilogue in fp32: ReLU, residual (reference: even i), BatchNorm as one FMA.  The accumulators carry the layer's
     //      weight scale 2^S; 2^-S rides on the residual FMA (even i) or is already folded into the BatchNorm scale of
@@ -357,8 +389,10 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __a
     }
     unsigned* const ggrp = reinterpret_cast<unsigned*>(c.red) + 4 * ((layer + 1) & 1);   // the reduction buffer is idle until the tail
     if (!last) guard_push(ggrp, c.w, c.lane, amax);
+    R8H_LTS(12)
 
     __syncthreads();  // every wave has finished reading this layer's input map
+    R8H_LTS(13)
     if (!last) {
         shift = __builtin_amdgcn_readfirstlane(range_shift(guard_read(ggrp)));   // uniform
         if (shift > 0) {   // never taken for trained models: keep it a (wave-uniform) branch, not selects on every value
@@ -375,7 +409,9 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __a
 #pragma unroll
             for (int m = 0; m < 3; ++m) store_split(c.qa[j] + es[m], acc[j][m]);
         if (c.xvalid) store_split(c.qa[5] + es[0], accx);
+        R8H_LTS(14)
         __syncthreads();
+        R8H_LTS(15)
     } else {
 #pragma unroll
         for (int m = 0; m < 3; ++m)
@@ -422,14 +458,6 @@ size_t res8h_lds_bytes() { return (size_t)X_LDS_BYTES; }
 // against 106 us per clip: the arbiters favour the older waves), hence the clip queue below.  A start-up stagger of the second
 // workgroup changes nothing (v8: second workgroup identified per physical CU -- HW_ID / XCC_ID arrival counters -- and
 // delays of 30 / 60 / 90 k ticks: 13.62 - 13.76 ms, noise).
-// phase timestamps for tools/r8_phases.py: build with -DR8H_TIMING (they overwrite the consumed feature rows)
-#ifdef R8H_TIMING
-#define R8H_TS_DECL unsigned long long ts[8], rt0 = __builtin_amdgcn_s_memrealtime();
-#define R8H_TS(i) ts[i] = __builtin_readcyclecounter();
-#else
-#define R8H_TS_DECL
-#define R8H_TS(i)
-#endif
 
 template <int TERMS>   // 3: fp32-accurate; 1: plain fp16 operands (KWS_DTYPE_F16)
 __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
@@ -465,6 +493,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
     // per cent as well.  The first clip is blockIdx.x; p.queue starts at gridDim.x.  The counter is read one clip ahead
     // (the atomic is in flight behind the feature loads) and published to the other waves through one LDS word.
     int* const next_clip = reinterpret_cast<int*>(ldsb + NEXT_OFF);
+    if (R8H_EPRIO) __builtin_amdgcn_s_setprio(R8H_EPRIO);
     for (int clip = blockIdx.x; clip < p.B;) {
         __syncthreads();  // previous clip's tail has consumed red/mvec and the map
         R8H_TS_DECL
@@ -710,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         R8H_TS(3)
 #pragma unroll 1   // one copy of the layer's code: the six inlined copies of round 2 made the kernel 66 KB, more than the instruction cache
         for (int layer = 0; layer < R8_LAYERS; ++layer) {
-            x_layer<TERMS>(p, c, ars, avoff, om, layer, clip, prev, prevx, shift, fa);
+            x_layer<TERMS>(p, c, ars, avoff, om, layer, clip, prev, prevx, shift, fa R8H_TSPASS);
 #ifdef R8H_TIMING
             if (layer == 0) { R8H_TS(4) }
             else if (layer == 1) { R8H_TS(5) }
@@ -720,12 +749,12 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         R8H_TS(7)
 #ifdef R8H_TIMING
         if ((threadIdx.x & 63) == 0) {      // the clip's features are dead: park the timestamps there (tools/r8_phases.py)
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.feat) + (size_t)clip * p.T * p.F) + 8 * w;
-            for (int i = 0; i < 8; ++i) o[i] = ts[i];
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.feat) + (size_t)clip * p.T * p.F) + 16 * w;
+            for (int i = 0; i < 16; ++i) o[i] = ts[i];
             if (w == 0) {   // 100 MHz wall clock over the same span: shader clock = d ticks / d realtime x 100 MHz
-                o[32] = rt0;
-                o[33] = __builtin_amdgcn_s_memrealtime();
-                o[34] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |   // XCC_ID
+                o[64] = rt0;
+                o[65] = __builtin_amdgcn_s_memrealtime();
+                o[66] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |   // XCC_ID
                         (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                        // HW_ID
             }
         }
