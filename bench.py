@@ -80,9 +80,21 @@ def build_model(torch, device):
     return model.to(device).eval(), sd_np
 
 
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(torch, wav_sample, sd, budget_s=12.0):
-    """Time the CPU oracle on host cores over a bounded sample (about 10-20 s of CPU work).  Returns the record and the
-    oracle's logits for the clips it evaluated (the parity check compares the GPU's logits with them)."""
+    """Time the CPU oracle on host cores over a bounded sample (about 10-20 s of CPU work on all granted threads, then ~4 s on
+    ONE thread).  Returns the record and the oracle's logits for the clips it evaluated (the parity check compares the GPU's
+    logits with them).  `wav_sample` is ordered so that every prefix of it straddles the whole batch."""
     import numpy as np
     from oracle import frontend, models    # bench-only use of oracle/: the checker and the timed CPU leg, never the product
     # the one-GPU box exposes every host core but grants a 16-worker share; stay inside the affinity mask and that share
@@ -103,26 +115,54 @@ def cpu_baseline(torch, wav_sample, sd, budget_s=12.0):
     outs = []
     t0 = time.perf_counter()
     for lo in range(0, n, 1024):
-        outs.append(run(x[lo:lo + 1024]))
+        outs.append(run(x[lo:min(lo + 1024, n)]))
     dt = time.perf_counter() - t0
     want = np.concatenate([np.asarray(o) for o in outs], 0)[:n]
+    # the same code on ONE thread (BASELINE.md section 4 asks for both figures): a bounded ~4 s sample
+    torch.set_num_threads(1)
+    run(x[:32])
+    t1 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t1 < 4.0 and n1 + 64 <= len(x):
+        run(x[n1:n1 + 64])
+        n1 += 64
+    dt1 = time.perf_counter() - t1
+    torch.set_num_threads(threads)
     rec = {"value": n / dt, "unit": "clips/s", "cores": threads, "kind": "port",
-           "sample": f"{n} of the benchmark's clips, chunks of 1024, numpy/scipy rFFT front end (fp32) + torch-CPU fp32 res8, {dt:.1f} s"}
+           "sample": f"{n} of the benchmark's clips (spread over the whole batch), chunks of 1024, numpy/scipy rFFT front end (fp32) + torch-CPU fp32 res8, {dt:.1f} s",
+           "one_thread": {"value": n1 / dt1, "unit": "clips/s", "cores": 1, "sample": f"{n1} clips in chunks of 64, {dt1:.1f} s"},
+           "cpu_model": cpu_model_string(), "host_cores_visible": os.cpu_count(),
+           "torch_parallel_info": torch.__config__.parallel_info().strip().split("\n")[0:4]}
     return rec, want
 
 
+def spread_indices(total, count):
+    """`count` clip indices spread evenly over [0, total), ordered so that every prefix is itself spread over the whole range
+    (the CPU leg evaluates a time-bounded prefix): index k of the even grid is visited in the order k * 7919 mod count."""
+    import numpy as np
+    grid = (np.arange(count, dtype=np.int64) * total) // count
+    order = (np.arange(count, dtype=np.int64) * 7919) % count
+    return grid[order]
+
+
 def secondary_configs(torch, device):
-    """BASELINE configs[2] (res15, `bf16`, B = 4096) and configs[4] (cnn-trad-pool2, `fp16`, B = 8192), features -> logits in their
-    own dtype on synthetic feature maps with the models' own initialisation: reported next to the headline, never mixed into it.
-    TFLOP/s are algorithmic (2 x MAC of the conv / linear stack), the roof is the dense 16-bit MFMA peak (single-term products)."""
+    """BASELINE configs[2] (res15, `bf16`, B = 4096) and configs[4] (cnn-trad-pool2, `fp16`, B = 8192) in their own dtype, with the
+    models' own initialisation on the benchmark's synthetic clips: wav -> logits (front end + model, the headline's path) and
+    features -> logits (the model alone), reported next to the headline and never mixed into it.  TFLOP/s are algorithmic
+    (2 x MAC of the conv / linear stack), the roof is the dense 16-bit MFMA peak (single-term products); for the layer-by-layer
+    res15 plan SURVEY.md 8(d)'s HBM-side roof (12.0 MB of bf16 activation traffic per clip) is quoted beside it.  `parity`
+    compares the first 256 clips with the fp32 CPU oracle at the dtype's tolerance, argmax on clips
+    whose oracle margin exceeds twice that tolerance."""
+    import numpy as np
     from honk2_amd.utils import find_cls
+    from oracle import frontend, models    # bench-only use of oracle/: the checker
     res15 = {"n_feature_maps": 45, "n_layers": 13, "use_dilation": True, "n_labels": 12}
     trad = {"time": 101, "frequency": 40, "dropout_prob": 0.5, "n_labels": 12,
             "conv_0": {"out_channels": 64, "kernel_size": [20, 8], "stride": [1, 1]}, "pool_0": {"kernel_size": [2, 2]},
             "conv_1": {"out_channels": 64, "kernel_size": [10, 4], "stride": [1, 1]}, "pool_1": {"kernel_size": [1, 1]}}
     out = []
-    for tag, name, cfg, dtype, batch, mflop in (("configs[2] res15 bf16", "ResNet", res15, "bf16", 4096, 1917.63),
-                                                ("configs[4] cnn-trad-pool2 fp16", "CNN", trad, "fp16", 8192, 192.37)):
+    for tag, name, cfg, dtype, batch, mflop, tol in (("configs[2] res15 bf16", "ResNet", res15, "bf16", 4096, 1917.63, 2e-2),
+                                                     ("configs[4] cnn-trad-pool2 fp16", "CNN", trad, "fp16", 8192, 192.37, 5e-3)):
         torch.manual_seed(7)
         model = find_cls(f"model.{name}")(dict(cfg, dtype=dtype))
         g = torch.Generator().manual_seed(1)
@@ -133,25 +173,124 @@ def secondary_configs(torch, device):
             elif k.endswith("running_var"):
                 sd[k] = 0.25 + 0.5 * torch.rand(v.shape, generator=g)
         model.load_state_dict(sd)
+        sd_np = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
         model = model.to(device).eval()
-        x = torch.randn(batch, 101, 40, device=device) * 2.5 + 0.65
-        for _ in range(2):
-            model(x)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        wav = synth_wav(torch, 0, batch, 1234, device)
+        feats = model.engine().mfcc(wav)
         reps = 5
-        torch.cuda.synchronize()
-        ev[0].record()
-        for _ in range(reps):
-            y = model(x)
-        ev[1].record()
-        torch.cuda.synchronize()
-        ms = ev[0].elapsed_time(ev[1]) / reps
-        out.append({"config": tag, "plan": model.plan_name(), "dtype": dtype, "batch": batch, "ms": ms, "clips_per_s": batch / ms * 1e3,
-                    "TFLOPs_alg": batch / ms * 1e3 * mflop * 1e6 / 1e12, "frac_of_2516_TFLOPs": batch / ms * 1e3 * mflop * 1e6 / 1e12 / 2516.0,
-                    "finite": bool(torch.isfinite(y).all().item()), "what": "features -> logits, own initialisation, synthetic feature maps"})
-        del model, x, y
+
+        def timed(fn):
+            for _ in range(2):
+                fn()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            torch.cuda.synchronize()
+            ev[0].record()
+            for _ in range(reps):
+                y = fn()
+            ev[1].record()
+            torch.cuda.synchronize()
+            return ev[0].elapsed_time(ev[1]) / reps, y
+
+        ms_wav, y = timed(lambda: model.forward_wav(wav))
+        ms_feat, yf = timed(lambda: model(feats))
+        nchk = 256
+        ofeats = frontend.compute_mfccs_batch(wav[:nchk].cpu().numpy(), "f32")
+        want = np.asarray(models.forward_torch(name, cfg, sd_np, ofeats))
+        got = y[:nchk].cpu().numpy()
+        err = np.abs(got - want)
+        top = np.sort(want, axis=1)
+        wide = (top[:, -1] - top[:, -2]) > 2.0 * tol
+        par = {"clips": nchk, "max_abs_err": float(err.max()), "tol": tol, "argmax_checked": int(wide.sum()),
+               "argmax_equal_on_checked": bool((got.argmax(1) == want.argmax(1))[wide].all()),
+               "against": "fp32 CPU oracle (numpy front end + torch-CPU model) on the same clips"}
+        par["pass"] = bool(np.isfinite(got).all() and par["max_abs_err"] <= tol and par["argmax_equal_on_checked"])
+        rate = batch / ms_feat * 1e3
+        rec = {"config": tag, "plan": model.plan_name(), "dtype": dtype, "batch": batch,
+               "wav_to_logits": {"ms": ms_wav, "clips_per_s": batch / ms_wav * 1e3},
+               "features_to_logits": {"ms": ms_feat, "clips_per_s": rate, "TFLOPs_alg": rate * mflop * 1e6 / 1e12,
+                                      "frac_of_2516_TFLOPs": rate * mflop * 1e6 / 1e12 / PEAK_BF16_MFMA_TFLOPS},
+               "parity": par, "finite": bool(torch.isfinite(y).all().item() and torch.isfinite(yf).all().item()),
+               "what": "own initialisation, the benchmark's synthetic clips; wav -> logits = front end + model, features -> logits = the model alone"}
+        if name == "ResNet":
+            # a layer-by-layer res15 in bf16 moves (13 x 2 + 6 + 1) x 363 600 B = 12.0 MB per clip
+            lw_bytes = (13 * 2 + 6 + 1) * 363600
+            rec["roofline_layerwise"] = {"bound": "hbm", "bytes_per_clip": lw_bytes, "peak_clips_per_s": PEAK_HBM_GBS * 1e9 / lw_bytes,
+                                         "achieved_clips_per_s": rate, "frac": rate * lw_bytes / (PEAK_HBM_GBS * 1e9),
+                                         "note": "SURVEY.md 8(d) secondary model: bf16 activation traffic of a layer-by-layer res15 against 8 TB/s"}
+        out.append(rec)
+        del model, wav, feats, y, yf
         torch.cuda.empty_cache()
     return out
+
+
+def shard_record(torch, model, device, full_rate, full_k_ms, full_f_ms, full_clips):
+    """The per-GPU workload of BASELINE configs[3] at 8 GPUs (65 536 / 8 = 8 192 clips) measured on this one GPU: wav -> logits,
+    20 steps; efficiency = its clip rate over the full batch's (1.0 = an 8-GPU run would hold the 1-GPU per-clip cost)."""
+    n = 8192
+    wav = synth_wav(torch, 0, n, 1234, device)
+    out = torch.empty((n, RES8["n_labels"]), dtype=torch.float32, device=device)
+    engine = model.engine()
+    for _ in range(3):
+        model.forward_wav(wav, out=out)
+    torch.cuda.synchronize()
+    engine.profile_enable(True)
+    engine.profile_read()
+    steps = 20
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.forward_wav(wav, out=out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k_ms, f_ms, calls = engine.profile_read()
+    engine.profile_enable(False)
+    k_ms, f_ms = k_ms / max(calls, 1), f_ms / max(calls, 1)
+    rate = n * steps / dt
+    return {"clips": n, "steps": steps, "ms_per_step": 1e3 * dt / steps, "clips_per_s": rate,
+            "res8_kernel_ms": k_ms, "frontend_kernel_ms": f_ms,
+            "efficiency_vs_full_batch": rate / full_rate,
+            "res8_kernel_efficiency": (full_k_ms / full_clips) / (k_ms / n) if k_ms > 0 else None,
+            "frontend_kernel_efficiency": (full_f_ms / full_clips) / (f_ms / n) if f_ms > 0 else None,
+            "projected_8gpu_speedup": 8.0 * rate / full_rate,
+            "what": "wav -> logits on 8 192 clips = one GPU's shard of the 8-GPU run (BASELINE configs[3]); the RCCL all-gather of 393 KB of logits is not in it"}
+
+
+def h2d_record(torch, model, device, nclips):
+    """The PCIe-inclusive variant SURVEY.md 8(d) asks for beside the headline (never `value`): the waveforms start in PINNED
+    host memory; chunks of 8 192 clips are copied on a second stream while the previous chunk computes."""
+    chunk = 8192
+    nclips = nclips // chunk * chunk
+    if nclips == 0:
+        return None
+    host = torch.empty((nclips, 16000), dtype=torch.float32).pin_memory()
+    host.normal_(0.0, 0.1)
+    bufs = [torch.empty((chunk, 16000), dtype=torch.float32, device=device) for _ in range(2)]
+    out = torch.empty((nclips, RES8["n_labels"]), dtype=torch.float32, device=device)
+    copy_s, comp_s = torch.cuda.Stream(device), torch.cuda.current_stream(device)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    freed = [torch.cuda.Event() for _ in range(2)]
+
+    def one_pass():
+        for i in range(nclips // chunk):
+            b = i & 1
+            with torch.cuda.stream(copy_s):
+                if i >= 2:
+                    copy_s.wait_event(freed[b])
+                bufs[b].copy_(host[i * chunk:(i + 1) * chunk], non_blocking=True)
+                ready[b].record(copy_s)
+            comp_s.wait_event(ready[b])
+            model.forward_wav(bufs[b], out=out[i * chunk:(i + 1) * chunk])
+            freed[b].record(comp_s)
+        torch.cuda.synchronize()
+
+    one_pass()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one_pass()
+    dt = (time.perf_counter() - t0) / reps
+    del host, bufs
+    return {"clips": nclips, "ms_per_pass": 1e3 * dt, "clips_per_s": nclips / dt, "h2d_GBps": nclips * 64000 / dt / 1e9,
+            "what": "wav in pinned host memory -> logits on the device, copies of 8 192-clip chunks overlapped with compute (two streams); PCIe-bound, reported beside `value`, never as it"}
 
 
 def parity_record(got, want, tol=1e-3):
@@ -181,6 +320,8 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="GLOBAL batch (clips per step over all GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] records (N = 1 only)")
+    ap.add_argument("--no-shard", action="store_true", help="skip the 8 192-clip shard record (N = 1 only)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the pinned-host (PCIe-inclusive) record (N = 1 only)")
     args = ap.parse_args()
 
     import torch
@@ -304,12 +445,24 @@ def main():
         }
         failed = False
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], want = cpu_baseline(torch, wav[:16384], sd)
-            out["parity"] = parity_record(logits[:len(want)].cpu().numpy(), want)
+            # the CPU leg evaluates a time-bounded prefix of a sample that is spread over the WHOLE batch (every 4th clip, in an
+            # order whose prefixes are spread too), and the parity check covers exactly those clips
+            idx = torch.from_numpy(spread_indices(nloc, min(16384, nloc))).to(device)
+            out["cpu_baseline"], want = cpu_baseline(torch, wav[idx], sd)
+            out["parity"] = parity_record(logits[idx[:len(want)]].cpu().numpy(), want)
+            out["parity"]["clip_index_range"] = [int(idx[:len(want)].min()), int(idx[:len(want)].max())]
             failed = not out["parity"]["pass"]
+        if world == 1 and not args.no_shard and args.batch >= 16384:
+            out["shard"] = shard_record(torch, model, device, clips_per_s, k_ms, f_ms, nloc)
+        if world == 1 and not args.no_h2d:
+            try:
+                out["h2d_inclusive"] = h2d_record(torch, model, device, min(args.batch, 32768))
+            except Exception as exc:
+                out["h2d_inclusive"] = {"error": repr(exc)}
         if world == 1 and not args.no_secondary:
             try:
                 out["secondary"] = secondary_configs(torch, device)
+                failed = failed or not all(r["parity"]["pass"] for r in out["secondary"])
             except Exception as exc:                   # never let an extra record take the headline line down
                 out["secondary"] = {"error": repr(exc)}
         dump = os.environ.get("KWS_BENCH_DUMP")        # tests: the (gathered) logits of the last step, for comparison across N
@@ -318,7 +471,7 @@ def main():
             np.save(dump, (gathered if world > 1 else logits).cpu().numpy())
         print(json.dumps(out))
         if failed:
-            raise SystemExit("parity check failed: " + json.dumps(out["parity"]))
+            raise SystemExit("parity check failed: " + json.dumps({"headline": out.get("parity"), "secondary": [r.get("parity") for r in out.get("secondary", []) if isinstance(r, dict)]}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -318,8 +318,18 @@ class Engine:
         return out
 
     def eval_batch(self, logits, target, stats, loss_sum):
+        import torch
         for t, what in ((logits, "logits"), (target, "target"), (stats, "stats"), (loss_sum, "loss_sum")):
             self._on_device(t, what)
+        n = self.desc.n_labels
+        if stats.dtype != torch.int64 or stats.numel() < 3 + 2 * n or not stats.is_contiguous():
+            raise ValueError(f"honk2_amd: stats must be a contiguous int64 tensor of at least 3 + 2 * n_labels = {3 + 2 * n} "
+                             f"words (ABI version 2: the last word counts out-of-range targets), got {stats.dtype} x {stats.numel()}")
+        if loss_sum.dtype != torch.float64 or loss_sum.numel() < 1:
+            raise ValueError("honk2_amd: loss_sum must be a float64 tensor")
+        if target.dtype != torch.int64 or target.numel() < logits.shape[0] or logits.dtype != torch.float32 \
+                or logits.dim() != 2 or logits.shape[1] != n or not logits.is_contiguous():
+            raise ValueError("honk2_amd: eval_batch takes contiguous float32 (B, n_labels) logits and int64 targets")
         check(self.lib.kws_eval_batch(self.handle, C.c_void_p(logits.data_ptr()), C.c_void_p(target.data_ptr()),
                                       logits.shape[0], C.c_void_p(stats.data_ptr()), C.c_void_p(loss_sum.data_ptr()),
                                       self._stream()), "kws_eval_batch")

@@ -208,7 +208,8 @@ bool conv_in1_supported(const ConvGeom& g, int ph, int pw) {
     const int ks = (g.kh + 3) / 4;
     return g.Cin == 1 && g.kw == 8 && g.ph == 0 && g.pw == 0 && g.dh == 1 && g.dw == 1 && g.W % 4 == 0 && g.W >= 8 &&
            (ks == 4 || ks == 5 || ks == 6 || ks == 8) && ph >= 1 && pw >= 1 && ph * pw <= 16 && g.Ho >= ph && g.Wo >= pw &&
-           conv_in1_lds_bytes(g.H, g.W, 2) <= 80 * 1024 - 256;
+           conv_in1_lds_bytes(g.H, g.W, 2) <= 80 * 1024 - 256 &&
+           3 * (g.W + 4) * 2 + 16 <= IN1_TAIL;   // the zero-weight kernel rows of the last output rows read this far past the last copy: keep it inside the zeroed tail
 }
 
 // weights (Cout, 1, kh, 8) x scale -> two fp16 parts, [group of MH tiles][k-step][MH][part][lane][8]; lane = (kernel row 4 s + g) << 4 | co

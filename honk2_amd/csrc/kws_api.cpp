@@ -59,8 +59,12 @@ enum LwMode { LW_FP32 = 0, LW_NCHW = 1, LW_TILED = 2 };
 
 struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the layer-wise plans
     ConvGeom g{};           // B/H/W/Ho/Wo filled per call for ResNet, at create for CNN
-    DevMem apk, apk16, apk16h, apk_t3h, bias, border, border_pad, w9cl, postab;   // postab: conv3x3_tile position table for postab_T frames
-    int postab_T = -1, postab_cpc[3] = {0, 0, 0};   // apk16h: fp16 fragments of the generic kernel; w9cl: conv_0 as [9 taps][C padded to 8] (conv0_cl_kernel)
+    DevMem apk, apk16, apk16h, apk_t3h, bias, border, border_pad, w9cl;
+    // conv3x3_tile position tables, one per clip length seen (never rewritten: an earlier call on a non-blocking stream may
+    // still be reading its table when the next clip length arrives)
+    struct PosTab { DevMem mem; int cpc[3] = {0, 0, 0}; };
+    std::map<int, std::unique_ptr<PosTab>> postabs;
+    // apk16h: fp16 fragments of the generic kernel; w9cl: conv_0 as [9 taps][C padded to 8] (conv0_cl_kernel)
     float x_scale = 1.f;     // 2^S of apk16h   // apk_t3h: fp16 fragments of the tiled 3x3 kernel
     float t3h_scale = 1.f;   // 2^S of apk_t3h   // border_pad: rows padded to a multiple of 8 channels (tiled kernel)
     bool has_bias = false, has_border = false, use_x = false;   // use_x: bf16x6 kernel available for this layer
@@ -597,7 +601,7 @@ size_t cnn_partial_bytes(const kws_handle* h, int cb) {
 
 size_t act_bytes(const kws_handle* h, int B, int T) {
     if (h->plan == PLAN_RESNET) {
-        if (use_fused(h, T)) return 0;
+        if (use_fused(h, T)) return h->res8_impl == 0 ? align256((size_t)B * sizeof(int)) : 0;   // per-clip feature shifts (kws_forward)
         const ResnetShape s = resnet_shape(h, T);
         const size_t full = (size_t)s.C * s.T * s.F, small = (size_t)s.C * s.H * s.W;
         if (resnet_tiled(h, s)) {   // three channels-last tensors (conv_0 writes the first one directly)
@@ -690,15 +694,16 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                 tp.Hs = (sh.H + dd - 1) / dd; tp.Ws = (sh.W + dd - 1) / dd;
                 tp.total = nb * dd * dd * tp.Hs * tp.Ws;
                 tp.rg = rg;
-                if (h->rconv[i].postab_T != T) {   // the per-cell table of this layer's geometry (once per clip length)
+                std::unique_ptr<ConvLayer::PosTab>& pt = h->rconv[i].postabs[T];
+                if (!pt) {   // the per-cell table of this layer's geometry: built and uploaded (blocking) on the FIRST call with this clip length
                     std::vector<int> tab;
-                    build_tile_conv_table(sh.H, sh.W, ld_in, ld_out, ld_x, tab, h->rconv[i].postab_cpc[0], h->rconv[i].postab_cpc[1],
-                                          h->rconv[i].postab_cpc[2]);
-                    if ((rc = h->rconv[i].postab.upload(tab.data(), tab.size() * sizeof(int)))) return rc;
-                    h->rconv[i].postab_T = T;
+                    std::unique_ptr<ConvLayer::PosTab> fresh(new ConvLayer::PosTab);
+                    build_tile_conv_table(sh.H, sh.W, ld_in, ld_out, ld_x, tab, fresh->cpc[0], fresh->cpc[1], fresh->cpc[2]);
+                    if ((rc = fresh->mem.upload(tab.data(), tab.size() * sizeof(int)))) { h->rconv[i].postabs.erase(T); return rc; }
+                    pt = std::move(fresh);
                 }
-                tp.postab = h->rconv[i].postab.as<int>();
-                tp.cpc_in = h->rconv[i].postab_cpc[0]; tp.cpc_out = h->rconv[i].postab_cpc[1]; tp.cpc_res = h->rconv[i].postab_cpc[2];
+                tp.postab = pt->mem.as<int>();
+                tp.cpc_in = pt->cpc[0]; tp.cpc_out = pt->cpc[1]; tp.cpc_res = pt->cpc[2];
                 static const int t3_dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
                 tp.debug = t3_dbg;
                 // KWS_T3_TIMING=<file> (timing builds only): phase stamps of layer KWS_T3_TIMING_LAYER (default 2) of the first chunk
@@ -755,7 +760,8 @@ int run_resnet_layerwise(kws_handle* h, const float* feat, int B, int T, float* 
         const int nb = std::min(cb, B - b0);
         auto pass = [&](int terms, RangeGate rg) -> int {
             int rcp;
-            // conv_0 + ReLU (+ AvgPool)
+            // conv_0 + ReLU (+ AvgPool); the features are split into fp16 parts too: note what fp16 cannot hold
+            if (rg.flag && !rg.gated) HIP_TRY(launch_range_check(feat + (size_t)b0 * sh.T * sh.F, (long long)nb * sh.T * sh.F, s, rg));
             ConvGeom g0 = h->rconv[0].g;
             set_spatial(g0, nb, sh.T, sh.F);
             ConvArgs a0{feat + (size_t)b0 * sh.T * sh.F, sh.pooled ? bufA : X, h->rconv[0].apk.as<float>(), nullptr, nullptr, nullptr, nullptr, rg};
@@ -949,7 +955,8 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
     return KWS_OK;
 }
 
-int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws_act, hipStream_t s) {
+// own_feat: the features come from this library's front end (log-mel values, far inside fp16's range)
+int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws_act, hipStream_t s, bool own_feat) {
     int rc;
     if ((rc = prof_mark(h, h->ev_model, s))) return rc;
     if (h->plan == PLAN_RESNET) {
@@ -964,6 +971,11 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 p.B = B; p.T = T; p.F = h->d.freq; p.n_labels = h->d.n_labels; p.debug = dbg;
                 p.terms = h->d.dtype == KWS_DTYPE_F16 ? 1 : 3;
                 p.queue = h->range_flag.as<unsigned>() + 16;   // (word 0 of that block is the layer-wise range flag)
+                if (!own_feat) {   // caller-provided features: any finite fp32 value (reference model/resnet.py:39-41)
+                    int* fsh = reinterpret_cast<int*>(ws_act);
+                    HIP_TRY(launch_feat_shift(feat, B, T * h->d.freq, fsh, s));
+                    p.feat_shift = fsh;
+                }
                 static const int r8_wgs = std::getenv("KWS_R8_WGS_PER_CU") ? std::atoi(std::getenv("KWS_R8_WGS_PER_CU")) : 2;
                 HIP_TRY(launch_res8h(p, std::min(B, r8_wgs * h->n_cu), s));
             } else if (h->res8_impl == 2) {
@@ -1234,7 +1246,7 @@ int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits,
     char* ws_act = need ? static_cast<char*>(h->ws) + (h->ws_bytes - need) : nullptr;
     if (ws_act) ws_act = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(ws_act) & ~(uintptr_t)255);
     return run_model(h, static_cast<const float*>(d_feat), B, T, static_cast<float*>(d_logits), ws_act,
-                     static_cast<hipStream_t>(stream));
+                     static_cast<hipStream_t>(stream), false);
 }
 
 static int forward_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, const float* d_noise, float noise_pct,
@@ -1249,7 +1261,7 @@ static int forward_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, 
     float* feat = static_cast<float*>(h->ws);
     if ((rc = mfcc_any(h, d_wav, d_pcm, d_noise, noise_pct, B, n_samples, feat, stream, clip_stride))) return rc;
     char* ws_act = ab ? static_cast<char*>(h->ws) + fb : nullptr;
-    return run_model(h, feat, B, T, d_logits, ws_act, static_cast<hipStream_t>(stream));
+    return run_model(h, feat, B, T, d_logits, ws_act, static_cast<hipStream_t>(stream), true);
 }
 
 int kws_forward_wav(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_logits, void* stream) {
@@ -1330,7 +1342,7 @@ int kws_forward_windows(kws_handle* h, const float* d_stream, size_t n_stream, i
     float* gbuf = h->ws_bytes >= fb + ab + gb ? reinterpret_cast<float*>(static_cast<char*>(h->ws) + fb + ab) : nullptr;
     if ((rc = mfcc_windows_impl(h, d_stream, window, shift, n_windows, feat, stream, gbuf))) return rc;
     char* ws_act = ab ? static_cast<char*>(h->ws) + fb : nullptr;
-    return run_model(h, feat, n_windows, T, d_logits, ws_act, static_cast<hipStream_t>(stream));
+    return run_model(h, feat, n_windows, T, d_logits, ws_act, static_cast<hipStream_t>(stream), true);
 }
 
 int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target, int B, int64_t* d_stats,

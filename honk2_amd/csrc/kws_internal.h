@@ -91,7 +91,7 @@ __device__ __forceinline__ bool range_gate_closed(const RangeGate& rg) {
     return rg.gated && rg.flag && __builtin_nontemporal_load(rg.flag) == 0u;
 }
 __device__ __forceinline__ void range_note(const RangeGate& rg, float amax) {
-    if (!rg.gated && rg.flag && amax >= KWS_RANGE_LIMIT) *rg.flag = 1u;   // same value from every writer: a benign race
+    if (!rg.gated && rg.flag && !(amax < KWS_RANGE_LIMIT)) *rg.flag = 1u;   // (a NaN flags too) same value from every writer: a benign race
 }
 #endif
 
@@ -220,8 +220,11 @@ struct Res8hParams {
     int debug;            // timing experiments only: 1 skip conv_0, 2 skip the MFMA loop
     int terms;            // 3: fp32-accurate products; 1: plain fp16 operands (KWS_DTYPE_F16)
     unsigned* queue;      // device word: next clip to hand out (launch_res8h sets it to the grid size)
+    const int* feat_shift;   // per clip: power of two its features are staged down by (launch_feat_shift), or nullptr = 0
 };
 size_t res8h_lds_bytes();
+// shift[b] = 0 while max |feat[b]| <= 2^14, else ceil(log2(max)) - 14: the fused kernel stages features as fp16 pairs
+hipError_t launch_feat_shift(const float* feat, int B, int n_per_clip, int* shift, hipStream_t s);
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s);
 void pack_res8h_layer(const float* w /*45x45x3x3*/, float scale, unsigned short* dst /*R8H_ASTEPS*3*2*64*8*/);
 void pack_res8h_conv0(const float* w /*45x9*/, float scale, unsigned short* dst /*(3*2 + 3)*64*8*/);

@@ -317,11 +317,13 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ in,
 // fp16 range guard for tensors the library does not produce itself (the feature maps handed to a CNN)
 __global__ __launch_bounds__(256) void range_check_kernel(const float* __restrict__ x, long long n, RangeGate rg) {
     float amax = 0.f;
+    bool odd = false;   // a NaN: fmaxf would drop it
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float v = x[i];
+        odd |= v != v;
         amax = fmaxf(amax, fabsf(v));
     }
-    range_note(rg, amax);
+    range_note(rg, odd ? INFINITY : amax);
 }
 
 hipError_t launch_range_check(const float* x, long long n, hipStream_t s, RangeGate rg) {

@@ -531,7 +531,11 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         for (int m = 0; m < 3; ++m) c.es[m] = (2 * c.cm[m] + (g >> 1)) * PLANE_B + 8 * (g & 1) - ga;
         c.xvalid = w < 3 && !((c.padmask >> 5) & 1);
 
-        // ---- stage the (101, 40) feature map as fp32 with a zero top row / left column, inside the idle map region
+        // ---- stage the (101, 40) feature map as fp16 pairs with a zero top row / left column, inside the idle map region.
+        //      Caller-provided features may exceed fp16's range (the reference takes any fp32 value, model/resnet.py:39-41):
+        //      p.feat_shift then holds, per clip, the power of two its features are scaled down by here; conv_0 + ReLU +
+        //      AvgPool commute with a positive scale, which the pool's multiplier undoes (exact both ways).
+        const int fshift = p.feat_shift ? __builtin_amdgcn_readfirstlane(p.feat_shift[clip]) : 0;
         {
             const f32x4* f4 = reinterpret_cast<const f32x4*>(p.feat + (size_t)clip * p.T * p.F);
             f32x4 v[4];
@@ -540,6 +544,11 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                 const int q4 = it * 256 + tid;
                 v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (q4 < 1010) v[it] = f4[q4];
+            }
+            if (fshift > 0) {   // (wave-uniform; never taken for log-mel features)
+                const float down = ldexpf(1.f, -fshift);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) v[it] *= down;
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                 }
             }
             const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float post = p.inv_scale0 * (1.0f / 12.0f);
+            const float post = p.inv_scale0 * (1.0f / 12.0f) * (fshift > 0 ? ldexpf(1.f, fshift) : 1.f);
             const char* fb = reinterpret_cast<const char*>(feat_w);
             // B fragments of pooling-window member (OY, OX) of the position whose window base is at byte address LB
 #define C0_FRAG(LB, OY, OX, BH, BL)                                                                            \
@@ -761,6 +770,26 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 #endif
         clip = *next_clip;   // written before the staging barrier of this clip; every wave reads it before the loop's top barrier
     }
+}
+
+// per clip: the power of two that brings max |feature| under 2^14 (0 for anything a front end produces); one wave per clip
+__global__ __launch_bounds__(256) void feat_shift_kernel(const float* __restrict__ feat, int B, int n4, int* __restrict__ shift) {
+    const int clip = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (clip >= B) return;
+    const f32x4* f4 = reinterpret_cast<const f32x4*>(feat) + (size_t)clip * n4;
+    float amax = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        const f32x4 v = f4[i];
+        amax = fmaxf(fmaxf(amax, fabsf(v[0])), fmaxf(fmaxf(fabsf(v[1]), fabsf(v[2])), fabsf(v[3])));
+    }
+    const unsigned m = wave_umax(__builtin_bit_cast(unsigned, amax));
+    if (lane == 0) shift[clip] = range_shift(__builtin_bit_cast(float, m));
+}
+
+hipError_t launch_feat_shift(const float* feat, int B, int n_per_clip, int* shift, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(feat_shift_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, feat, B, n_per_clip / 4, shift);
+    return hipGetLastError();
 }
 
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s) {

@@ -460,6 +460,35 @@ def test_layerwise_fp16_range_guard(torch_cuda, case):
     assert torch.equal(model(x[:n_clean]), torch.from_numpy(got[:n_clean]).cuda())     # the clean chunk kept its fp16 pass
 
 
+def test_fused_res8_takes_any_fp32_feature_range(torch_cuda):
+    """The reference's ResNet.forward takes any finite fp32 feature (model/resnet.py:39-41); the fused res8 kernel stages features
+    as fp16 pairs.  kws_forward therefore measures every clip's feature range on the device and the kernel stages out-of-range
+    clips scaled down by a power of two that conv_0's pooling multiplier undoes (exact): clips whose features were blown up by
+    40 000 (and by 3e7, beyond fp16's 65 504 many times over) match fp32 arithmetic to rounding error, clean clips in the same
+    batch stay bit-identical to running them alone, and the fused plan is the one that ran."""
+    torch = torch_cuda
+    from oracle import models, weights
+    cfg = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 12}
+    sd = weights.make_state_dict("ResNet", cfg, seed=5)
+    n_clean, n = 600, 1100
+    feats = weights.make_features(n, seed=9)
+    feats[n_clean:900] *= 40000.0
+    feats[900:] *= 3.0e7
+    model = _build(torch, "ResNet", cfg, sd)
+    x = torch.from_numpy(feats).cuda()
+    got = model(x).cpu().numpy()
+    assert model.plan_name() == "res8_fused"
+    want = models.forward_torch("ResNet", cfg, sd, feats).numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got[:n_clean] - want[:n_clean]).max() < LOGIT_TOL
+    for lo, hi in ((n_clean, 900), (900, n)):
+        big = np.abs(want[lo:hi]).max()
+        assert big > 3e3, big
+        assert np.abs(got[lo:hi] - want[lo:hi]).max() < 3e-6 * big, (np.abs(got[lo:hi] - want[lo:hi]).max(), big)
+        assert (got[lo:hi].argmax(1) == want[lo:hi].argmax(1)).mean() > 0.99
+    assert torch.equal(model(x[:n_clean]), torch.from_numpy(got[:n_clean]).cuda())
+
+
 def test_wav_to_logits_end_to_end(torch_cuda):
     torch = torch_cuda
     from oracle import frontend, models, weights
