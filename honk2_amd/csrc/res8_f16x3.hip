@@ -243,6 +243,9 @@ __device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag&
 #ifndef R8H_EPRIO   // wave priority OUTSIDE the k-loops (epilogues, conv_0, staging, tail)
 #define R8H_EPRIO 0
 #endif
+#ifndef R8H_ORDER    // MFMA order inside a (k-step, position tile): 0 chain-major, 1 term-major
+#define R8H_ORDER 0
+#endif
 #ifndef R8H_BDEPTH   // position tiles of look-ahead of the k-loop's LDS reads
 #define R8H_BDEPTH 1
 #endif
@@ -271,13 +274,12 @@ __device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag&
 // One conv_i + epilogue (i = layer + 1).  `fa0` arrives holding k-step 0's weight fragments (requested before the previous
 // epilogue and its barriers) and leaves holding the next layer's.
 template <int TERMS>
-__device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __amdgpu_buffer_rsrc_t ars, int avoff, const int (&om)[3],
-                                        const int layer, const int clip, f32x4 (&prev)[5][3], f32x4& prevx, int& shift,
-                                        AFrags (&fa)[2] R8H_TSARG) {
+__device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_buffer_rsrc_t ars, int& avoff, const int (&om)[3],
+                                        const int layer, f32x4 (&acc)[5][3], f32x4& accx, f32x4 (&prev)[5][3], f32x4& prevx,
+                                        int& shift, AFrags (&fa)[2] R8H_TSARG) {
     const bool even = layer & 1, last = layer == R8_LAYERS - 1;   // reference layer i = layer + 1: residual on even i
     const int g = c.g;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[5][3], accx;
     constexpr int NB = R8H_BDEPTH + 1;
     BFrag bb[NB];   // ring over the (k-step, position tile) sequence
     if (R8H_ABLATE)
@@ -287,8 +289,9 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __a
     const int sb = layer * A_LAYER_B;
     // per-lane offsets are re-materialised per layer from opaque copies: left alone, LICM hoists every sum built from them
     // (store addresses, k-slot bases, table addresses: ~40 registers) out of the layer loop and the allocator spills them
-    int dB = c.dB, dC = c.dC, dD = c.dD, es[3] = {c.es[0], c.es[1], c.es[2]};
-    asm volatile("" : "+v"(dB), "+v"(dC), "+v"(dD), "+v"(es[0]), "+v"(es[1]), "+v"(es[2]), "+v"(avoff));
+    // (in place: a separate copy would keep both values alive across the loop)
+    asm volatile("" : "+v"(c.dB), "+v"(c.dC), "+v"(c.dD), "+v"(c.es[0]), "+v"(c.es[1]), "+v"(c.es[2]), "+v"(avoff));
+    const int dB = c.dB, dC = c.dC, dD = c.dD, es[3] = {c.es[0], c.es[1], c.es[2]};
     if (!(p.debug & 2)) {
         // B fragments are fetched R8H_BDEPTH position tiles ahead (2 ds_read_b128 per tile; the LDS counter is 4 bits, a
         // whole k-step's reads cannot be outstanding); A fragments one k-step ahead, the last step requests the next layer's
@@ -311,10 +314,20 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __a
                 if (!(R8H_ABLATE && (p.debug & 4)) && tn < 6 * KSTEPS) load_b(bb[tn % NB], c.qa, dB, dC, dD, tn / 6, tn % 6);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 5) {
+                    if (s == 0) acc[j][0] = acc[j][1] = acc[j][2] = zero;
+                    if (R8H_ORDER == 0 || TERMS < 3) {   // chain-major: the three terms of an accumulator back to back
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        if (s == 0) acc[j][m] = zero;
-                        mf_tile<TERMS>(s, fc.a[m], bcur, acc[j][m]);
+                        for (int m = 0; m < 3; ++m) mf_tile<TERMS>(s, fc.a[m], bcur, acc[j][m]);
+                    } else {                             // term-major: one B fragment meets the three slots' A fragments in turn
+                        const bool kd = step_kind(s) == 3;
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) { MF(fc.a[m][1], bcur.p[kd ? 1 : 0], acc[j][m]); }
+                        if (!kd) {
+#pragma unroll
+                            for (int m = 0; m < 3; ++m) { MF(fc.a[m][0], bcur.p[1], acc[j][m]); }
+                        }
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) { MF(fc.a[m][0], bcur.p[0], acc[j][m]); }
                     }
                 } else if (c.w < 3) {   // wave 3 owns no extra tile
                     if (s == 0) accx = zero;
@@ -338,7 +351,9 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __a
     // ---- epilogue in fp32: ReLU, residual (reference: even i), BatchNorm as one FMA.  The accumulators carry the layer's
     //      weight scale 2^S; 2^-S rides on the residual FMA (even i) or is already folded into the BatchNorm scale of
     //      the table (odd i).
-    const float* bt = c.bnt + layer * 96 + 4 * g;
+    int gq = 4 * g;
+    asm volatile("" : "+v"(gq));   // (the table addresses are built here, per layer, not hoisted and spilled)
+    const float* bt = c.bnt + layer * 96 + gq;
     const float up = shift > 0 ? ldexpf(1.f, shift) : 1.f;   // undo the range guard of the map this layer read (uniform)
     const float inv = p.inv_scale[layer] * up;
     float amax = 0.f;
@@ -412,39 +427,60 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, const XCtx& c, __a
         R8H_LTS(14)
         __syncthreads();
         R8H_LTS(15)
-    } else {
+    }
+}
+// spatial mean of the last layer's (BatchNorm'ed) output + Linear(45, n_labels): 16-lane shuffles, one LDS combine over the
+// four waves, n_labels threads.  Its own function, called after the layer loop: inside the loop its lane-derived addresses
+// were hoisted to the loop's front and spilled.
+__device__ __forceinline__ void x_tail(const Res8hParams& p, const XCtx& c0, const unsigned short* pos_tab, const int clip,
+                                       const f32x4 (&acc)[5][3], const f32x4& accx) {
+    // (lane-derived values rebuilt from the thread id: kept alive across the layer loop they were spilled)
+    struct { int tid, pcol, w, padmask; bool xvalid; float* red; float* mvec; int cm[3]; } c;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    c.tid = tid;
+    c.pcol = tid & 15;
+    c.w = c0.w;
+    c.red = c0.red;
+    c.mvec = c0.mvec;
+    c.padmask = 0;
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+    for (int j = 0; j < 6; ++j) c.padmask |= (pos_tab[16 * (j < 5 ? 5 * c.w + j : 20) + c.pcol] >> 15) << j;
+    c.xvalid = c.w < 3 && !((c.padmask >> 5) & 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = 0.f;
+    for (int m = 0; m < 3; ++m) c.cm[m] = c0.cm[m];
+    const int g = (tid & 63) >> 4;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) v += (c.padmask >> j) & 1 ? 0.f : acc[j][m][r];   // a pad lane's position is counted by the lane it clones
-                v += __shfl_xor(v, 8);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 1);
-                if (c.pcol == 0) c.red[c.w * 48 + 16 * c.cm[m] + 4 * g + r] = v;
-            }
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v = c.xvalid ? accx[r] : 0.f;
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) v += (c.padmask >> j) & 1 ? 0.f : acc[j][m][r];   // a pad lane's position is counted by the lane it clones
             v += __shfl_xor(v, 8);
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 1);
-            if (c.pcol == 0 && c.w < 3) c.red[c.w * 48 + 16 * c.cm[0] + 4 * g + r] += v;
+            if (c.pcol == 0) c.red[c.w * 48 + 16 * c.cm[m] + 4 * g + r] = v;
         }
-        __syncthreads();
-        if (c.tid < 48)
-            c.mvec[c.tid] = (c.red[c.tid] + c.red[48 + c.tid] + c.red[96 + c.tid] + c.red[144 + c.tid]) / (float)R8_NPOS;
-        __syncthreads();
-        if (c.tid < p.n_labels) {
-            const float* wr = p.out_w + c.tid * R8_C;
-            float o = 0.f;
-            for (int ch = 0; ch < R8_C; ++ch) o = fmaf(wr[ch], c.mvec[ch], o);
-            p.logits[(size_t)clip * p.n_labels + c.tid] = o + p.out_b[c.tid];
-        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = c.xvalid ? accx[r] : 0.f;
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        if (c.pcol == 0 && c.w < 3) c.red[c.w * 48 + 16 * c.cm[0] + 4 * g + r] += v;
+    }
+    __syncthreads();
+    if (c.tid < 48)
+        c.mvec[c.tid] = (c.red[c.tid] + c.red[48 + c.tid] + c.red[96 + c.tid] + c.red[144 + c.tid]) / (float)R8_NPOS;
+    __syncthreads();
+    if (c.tid < p.n_labels) {
+        const float* wr = p.out_w + c.tid * R8_C;
+        float o = 0.f;
+        for (int ch = 0; ch < R8_C; ++ch) o = fmaf(wr[ch], c.mvec[ch], o);
+        p.logits[(size_t)clip * p.n_labels + c.tid] = o + p.out_b[c.tid];
     }
 }
 }  // namespace
@@ -614,7 +650,9 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                 }
             }
             const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float post = p.inv_scale0 * (1.0f / 12.0f) * (fshift > 0 ? ldexpf(1.f, fshift) : 1.f);
+            float is0 = p.inv_scale0;
+            asm volatile("" : "+s"(is0));   // (computed here, per clip: hoisted to the kernel's front the product sat in a spilled VGPR)
+            const float post = is0 * (1.0f / 12.0f) * (fshift > 0 ? ldexpf(1.f, fshift) : 1.f);
             const char* fb = reinterpret_cast<const char*>(feat_w);
             // B fragments of pooling-window member (OY, OX) of the position whose window base is at byte address LB
 #define C0_FRAG(LB, OY, OX, BH, BL)                                                                            \
@@ -705,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         // every wave is done with the staged features: turn the region back into a map -- zero halo, then the pooled conv_0
         // output in its interior
         int shift;   // range guard of the map the next layer reads
-        const int avoff = lane * 16;
+        int avoff = lane * 16;
         AFrags fa[2];
         load_a(fa[0], ars, avoff, 0, om);   // conv_1's first weight fragments
         {
@@ -746,15 +784,17 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         __syncthreads();
 
         R8H_TS(3)
+        f32x4 acc[5][3], accx;
 #pragma unroll 1   // one copy of the layer's code: the six inlined copies of round 2 made the kernel 66 KB, more than the instruction cache
         for (int layer = 0; layer < R8_LAYERS; ++layer) {
-            x_layer<TERMS>(p, c, ars, avoff, om, layer, clip, prev, prevx, shift, fa R8H_TSPASS);
+            x_layer<TERMS>(p, c, ars, avoff, om, layer, acc, accx, prev, prevx, shift, fa R8H_TSPASS);
 #ifdef R8H_TIMING
             if (layer == 0) { R8H_TS(4) }
             else if (layer == 1) { R8H_TS(5) }
             else if (layer == 4) { R8H_TS(6) }
 #endif
         }
+        x_tail(p, c, pos_tab, clip, acc, accx);
         R8H_TS(7)
 #ifdef R8H_TIMING
         if ((threadIdx.x & 63) == 0) {      // the clip's features are dead: park the timestamps there (tools/r8_phases.py)

@@ -848,3 +848,11 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(torch_cuda, tmp_path):
     assert line1["n_gpus"] == 1 and line1["config"]["clips_per_gpu"] == 2048
     a, b = np.load(tmp_path / "n1.npy"), np.load(tmp_path / "n2.npy")
     assert a.shape == b.shape == (2048, 12) and np.array_equal(a, b)
+    # the RCCL leg gathers on a side stream while the next step computes (two buffers in rotation): the same stream / event logic
+    # with a device copy standing in for the collective must hand back the last step's logits
+    env3 = dict(os.environ, KWS_BENCH_DUMP=str(tmp_path / "n1g.npy"), KWS_BENCH_SELF_GATHER="1")
+    for steps in ("2", "3"):
+        sg = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", steps, "--warmup", "1",
+                             "--batch", "2048", "--no-cpu-baseline", "--no-secondary"], env=env3, capture_output=True, text=True, timeout=600, cwd=root)
+        assert sg.returncode == 0, sg.stderr[-2000:]
+        assert np.array_equal(np.load(tmp_path / "n1g.npy"), a)

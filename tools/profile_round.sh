@@ -1,14 +1,14 @@
 #!/bin/bash
-# Round-2 profiles (run on the GPU box from the repo root): rocprofv3 kernel stats of the default bench command, PMC passes for
-# its two kernels, and kernel stats + PMC of BASELINE configs[2] / [4] in their own dtype.  Summaries -> profiles/r02 (tools/summarize_prof.py)
+# Per-round profiles (run on the GPU box from the repo root: tools/profile_round.sh <tag> [round dir, default r03]): rocprofv3 kernel stats of the default bench command, PMC passes for
+# its two kernels, and kernel stats + PMC of BASELINE configs[2] / [4] in their own dtype.  Summaries -> gpurun_out/prof_<tag>*; tools/summarize_prof.py <dir> <tag> profiles/<round> turns them into the committed files
 tag=${1:-v9}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/prof_$tag
 mkdir -p $out
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 > $out.stats.log 2>&1 || { echo stats failed; tail -3 $out.stats.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-shard --no-h2d > $out.stats.log 2>&1 || { echo stats failed; tail -3 $out.stats.log; exit 1; }
 n=1
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $ctrs -d $out/pmc$n --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $out.pmc$n.log 2>&1 || { echo "pmc $n failed"; tail -3 $out.pmc$n.log; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $ctrs -d $out/pmc$n --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-shard --no-h2d > $out.pmc$n.log 2>&1 || { echo "pmc $n failed"; tail -3 $out.pmc$n.log; exit 1; }
   n=$((n+1))
 done
 for cfg in "res15_bf16:bf16:4096:resnet__res15" "cnn_fp16:fp16:8192:cnn__cnn-trad-pool2" "res15_f32:f32:2048:resnet__res15"; do

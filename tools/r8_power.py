@@ -34,11 +34,16 @@ def sample():
         time.sleep(0.3)
 th = threading.Thread(target=sample); th.start()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-reps = 250
+reps = int(os.environ.get("R8_REPS", "250"))
 ev[0].record()
 for _ in range(reps): y = model(x)
 ev[1].record(); torch.cuda.synchronize()
 stop = True; th.join()
 ms = ev[0].elapsed_time(ev[1]) / reps
-print(json.dumps({"zero": zero, "ms": round(ms, 3), "checksum": float(y.double().abs().sum())}))
-for s in samples[2:6]: print(s)
+import re
+pw = [float(m.group(1)) for smp in samples[2:] for m in [re.search(r'Package Power \(W\)": "([0-9.]+)"', smp)] if m]
+ck = [float(m.group(1)) for smp in samples[2:] for m in [re.search(r'sclk clock speed:": "\(([0-9.]+)Mhz', smp)] if m]
+pw_m = sum(pw) / max(len(pw), 1); ck_m = sum(ck) / max(len(ck), 1)
+print(json.dumps({"zero": zero, "debug": os.environ.get("KWS_R8_DEBUG", "0"), "lib": os.path.basename(os.environ.get("KWS_LIB", "default")),
+                  "ms": round(ms, 3), "power_W": round(pw_m, 1), "sclk_MHz": round(ck_m), "uJ_per_clip": round(pw_m * ms * 1e-3 / B * 1e6, 1),
+                  "samples": len(pw)}))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Reduce rocprofv3 CSV output (kernel stats + PMC counter collections) to the kws_* kernels and print/save a
-compact per-kernel summary.  Usage: tools/summarize_prof.py <gpurun_out dir> <tag> -> profiles/r01/<tag>_*.csv|json"""
+compact per-kernel summary.  Usage: tools/summarize_prof.py <gpurun_out dir> <tag> [profiles/<round>] -> <tag>_kernel_stats.csv, <tag>_summary.json"""
 import collections
 import csv
 import glob
@@ -9,7 +9,7 @@ import os
 import sys
 
 
-def main(src, tag, dst="profiles/r02"):
+def main(src, tag, dst="profiles/r03"):
     os.makedirs(dst, exist_ok=True)
     summary = {}
     for path in glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True):
