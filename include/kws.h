@@ -22,15 +22,23 @@
  *     library BORROWS them for the duration of the call and never frees them).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every compute call is
  *     asynchronous on that stream and performs no host synchronisation and no allocation, so a call
- *     sequence can be captured into a hipGraph.
+ *     sequence can be captured into a hipGraph -- with two one-time exceptions, both on the FIRST compute
+ *     call that needs them (so: run one un-captured warm-up call per clip length first): the re-packed
+ *     parameters are uploaded when the first call after kws_load_weights finalises them, and the tiled
+ *     ResNet plan (res15 / res26 / narrow models, res8 on clips that are not one second long) builds and
+ *     uploads a per-layer position table the first time it sees a clip length T (blocking copies into
+ *     buffers of their own; tables of earlier clip lengths are kept and never rewritten).
  *   - every function returns 0 (KWS_OK) or a negative KWS_E* code; kws_last_error() returns a
  *     thread-local human-readable message for the last failure on the calling thread.
  *   - a handle is bound to the HIP device that was current at kws_create and is not re-entrant
  *     (one in-flight call per handle); distinct handles are independent.
  *   - KWS_DTYPE_F32: results are fp32-accurate (fp32 accumulation everywhere).  Products are formed on the 16-bit matrix cores
  *     from split fp32 operands: three exact fp16 x fp16 terms of two-part fp16 splits (weights pre-scaled by a power of two per
- *     layer; error <= 3 * 2^-22 |ab|, measured as close to a float64 evaluation as an fp32 implementation; activations must
- *     stay below 65504 in magnitude), or -- KWS_RES8_IMPL=bf16x6 -- six bf16 x bf16 terms of three-part bf16 splits.
+ *     layer; error <= 3 * 2^-22 |ab|, measured as close to a float64 evaluation as an fp32 implementation), or --
+ *     KWS_RES8_IMPL=bf16x6 -- six bf16 x bf16 terms of three-part bf16 splits.  fp16's range (65504) is no restriction on the
+ *     caller: features and activations take any finite fp32 value, as in the reference -- the fused res8 kernel stages
+ *     out-of-range feature clips and maps scaled by a power of two (exact), the layer-wise plans recompute a chunk whose
+ *     activations leave fp16's range on three-part bf16 operands; both without a host round trip.
  *     The front end's DFT uses the same three-term fp16 products with the samples scaled by a power of two per clip chunk
  *     (any finite sample magnitude is fine); KWS_FRONTEND_IMPL=fp32 selects its fp32-input matrix-core form, which also
  *     serves waveform rows that are not 16-byte aligned.
