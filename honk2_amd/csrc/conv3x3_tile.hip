@@ -520,6 +520,262 @@ void build_tile_conv_table(int H, int W, int ld_in, int ld_out, int ld_res, std:
     }
 }
 
+// ------------------------------------------------------------------------------------------------ two layers in one kernel
+// conv_i (odd i) -> ReLU -> [BatchNorm folded into conv_{i+1}] -> conv_{i+1} -> ReLU -> + x_{i-1}, for consecutive layers of EQUAL
+// dilation on 16-bit tensors (the `bf16` / `fp16` dtypes: res15's pairs (1,2) (5,6) (7,8) (11,12), reference model/resnet.py:20-26,
+// 46-55).  Those layers are bound by their bytes, not by their MFMAs (profiles/r02/final_res15_bf16_summary.json: 3.1 TB/s, matrix pipe
+// 25 % busy), and the odd layer's output y_i has exactly one consumer.  So a workgroup stages the input tile with a halo of TWO
+// rows, computes y_i on the output tile + ONE halo row straight into a second LDS region (same 96-byte cells, same rounding to
+// the tensor type as the store it replaces: results are bit-identical to the two-kernel form), and runs conv_{i+1} from there.
+// x_{i-1} is at once conv_i's input and conv_{i+1}'s residual, and in layout(d) both layers address it identically: the residual
+// is read from the staged tile, not from memory.  Per pair: read 1.5 - 1.9 x + write 1 x instead of (1.26 + 1) + (1.26 + 1 + 1) tensor
+// passes, one launch instead of two; the halo row of y_i is computed twice (the matrix pipe has the room).
+// JTB: output position tiles per wave (TILE = 64 JTB positions); a wave takes up to 5 tiles of the intermediate map (<= 320 cells).
+struct PairKStep { int off, tap; };
+template <int NB, int MT, bool F16, int JT>
+__device__ __forceinline__ void pair_kloop(const char* lds, const int zero_off, const int2_* ktab, const __amdgpu_buffer_rsrc_t ars,
+                                           const int avoff, const int (&lbase)[JT], const int (&tmask)[JT], f32x4 (&acc)[JT][MT]) {
+    constexpr int WP = F16 ? 2 : 3;                 // parts per weight fragment group as packed on the host (part 0 is used)
+    constexpr int STEPS = (9 * NB + 3) / 4;
+    auto b_addr = [&](int j, int2_ e) {
+        const int m = __builtin_amdgcn_sbfe(tmask[j], e[1], 1);      // 0 or -1: a dead tap reads the shared zero cell
+        return zero_off + ((lbase[j] + e[0]) & m);
+    };
+    auto load_a = [&](u32x4 (&ar)[MT], int s) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            ar[m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff, ((s * MT + m) * WP) * 1024, 0));
+    };
+    u32x4 a[2][MT], bb[2];
+    int2_ e_c = ktab[0];
+    load_a(a[0], 0);
+    bb[0] = *reinterpret_cast<const u32x4*>(lds + b_addr(0, e_c));
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        int2_ e_n = e_c;
+        if (s + 1 < STEPS) {
+            e_n = ktab[4 * (s + 1)];
+            load_a(a[(s + 1) & 1], s + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const int t = s * JT + j;
+            if (j + 1 < JT) bb[(t + 1) & 1] = *reinterpret_cast<const u32x4*>(lds + b_addr(j + 1, e_c));
+            else if (s + 1 < STEPS) bb[(t + 1) & 1] = *reinterpret_cast<const u32x4*>(lds + b_addr(0, e_n));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (s == 0) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (F16) TMFH(a[s & 1][m], bb[t & 1], acc[j][m]);
+                else TMF(a[s & 1][m], bb[t & 1], acc[j][m]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        e_c = e_n;
+    }
+}
+
+template <int NB, int MT, bool F16, int JTB>
+__global__ __launch_bounds__(256, 2) void conv3x3_pair_kernel(PairConvParams p) {
+    constexpr int CELL = NB * 16;                   // one 16-bit part: LDS cell = global cell
+    constexpr int STEPS = (9 * NB + 3) / 4;
+    constexpr int TILE_P = 64 * JTB, JTA = 5;
+    constexpr int NQ = NB, NGRP = 256 / NQ;
+    extern __shared__ __align__(16) char lds[];
+    if (range_gate_closed(p.rg)) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, pcol = lane & 15;
+    const int Ws = p.Ws, halo = Ws + 1;
+    int tile_id = (int)blockIdx.x;
+    {   // blocks that share an XCD take a contiguous run of tiles (halo re-reads hit that L2)
+        const int nwg = (int)gridDim.x, xcd = tile_id & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile_id >> 3);
+    }
+    const int P0 = tile_id * TILE_P;
+    const int n_in = TILE_P + 4 * halo, n_mid = TILE_P + 2 * halo;      // cells of the input tile / of y_i
+    const int mid_off = n_in * CELL;
+    const int zero_off = mid_off + n_mid * CELL;
+    const int border_off = zero_off + CELL + 512;   // [2][16 classes][NB*8] floats
+    const float inv_cpc = 1.0f / (float)p.cpc_in;
+
+    // ---- table entries of this lane's positions: outputs (conv_b) and intermediate cells (conv_a); both layers share the layout
+    i32x4 peb[JTB];
+    int pbb[JTB];
+#pragma unroll
+    for (int j = 0; j < JTB; ++j) {
+        const int P = min(P0 + (w * JTB + j) * 16 + pcol, p.total - 1);
+        int q;
+        pbb[j] = fdiv(P, p.cpc_in, inv_cpc, q);
+        peb[j] = *reinterpret_cast<const i32x4*>(p.postab + 4 * q);
+    }
+    int pea[JTA];
+#pragma unroll
+    for (int j = 0; j < JTA; ++j) {
+        const int lm = (w * JTA + j) * 16 + pcol;
+        const int Pm = P0 - halo + lm;
+        int q;
+        (void)fdiv(min(max(Pm, 0), p.total - 1), p.cpc_in, inv_cpc, q);
+        pea[j] = p.postab[4 * q];
+    }
+    // ---- stage cells [P0 - 2 halo, P0 + TILE_P + 2 halo), tables
+    {
+        const int qd = tid % NQ, grp = tid / NQ;
+        if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + zero_off + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+        if (tid < 4 * (STEPS + 2)) {
+            const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
+            reinterpret_cast<int2_*>(lds + zero_off + CELL)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16 - zero_off, tap < 9 ? tap : 31};
+        }
+        for (int t = tid; t < 2 * 32 * NB; t += 256) {
+            const int which = t / (32 * NB), r = t - which * 32 * NB;
+            const float* src = which ? p.border_b : p.border_a;
+            f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (src) bv = *reinterpret_cast<const f32x4*>(src + 4 * r);
+            *reinterpret_cast<f32x4*>(lds + border_off + 16 * t) = bv;
+        }
+        if (grp < NGRP) {
+            const char* src = reinterpret_cast<const char*>(p.in);
+            constexpr int UNR = 10;   // (TILE_P + 4 halo) / 42 cells per pass: all of a thread's loads in flight together
+            for (int i0 = grp; i0 < n_in; i0 += UNR * NGRP) {
+                f32x4 v[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int q = min(max(P0 - 2 * halo + i0 + u * NGRP, 0), p.total - 1);   // (cells that are never tapped: clamped, not tested)
+                    v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)q * CELL + qd * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int i = i0 + u * NGRP;
+                    if (i < n_in) *reinterpret_cast<f32x4*>(lds + i * CELL + qd * 16) = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t ars_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk_a), 0, STEPS * MT * (F16 ? 2 : 3) * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk_b), 0, STEPS * MT * (F16 ? 2 : 3) * 1024, 0x00020000);
+    const int2_* const ktab = reinterpret_cast<const int2_*>(lds + zero_off + CELL) + g;
+    float amax = 0.f;
+    // ---------------------------------------------------------------- conv_i on the intermediate cells -> LDS
+    {
+        int lbase[JTA], tmask[JTA];
+#pragma unroll
+        for (int j = 0; j < JTA; ++j) {
+            const int lm = (w * JTA + j) * 16 + pcol;
+            const int Pm = P0 - halo + lm;
+            lbase[j] = (lm + halo) * CELL;                                   // its cell in the input tile
+            tmask[j] = (lm < n_mid && Pm >= 0 && Pm < p.total) ? pea[j] : 0;   // outside: no live tap, never read by conv_b either
+        }
+        f32x4 acc[JTA][MT];
+        pair_kloop<NB, MT, F16, JTA>(lds, zero_off, ktab, ars_a, lane * 16, lbase, tmask, acc);
+#pragma unroll
+        for (int j = 0; j < JTA; ++j) {
+            const int lm = (w * JTA + j) * 16 + pcol;
+            if (lm >= n_mid) continue;
+            const int bmask = (tmask[j] >> 9) & 15;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = m * 16 + 4 * g;
+                if (co0 >= NB * 8) continue;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(lds + border_off + (bmask * (NB * 8) + co0) * 4);
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = relu1(fmaf(acc[j][m][r], p.inv_scale_a, bb[r]));
+                    v[r] = (co0 + r < p.Cout && ((tmask[j] >> 13) & 1)) ? x : 0.f;
+                    amax = fmaxf(amax, fabsf(v[r]));
+                }
+                *reinterpret_cast<u32x2*>(lds + mid_off + lm * CELL + co0 * 2) = cl_pack4<F16>(v);
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- conv_{i+1} from the intermediate cells, + x_{i-1}, -> memory
+    {
+        int lbase[JTB], tmask[JTB];
+#pragma unroll
+        for (int j = 0; j < JTB; ++j) {
+            const int local = (w * JTB + j) * 16 + pcol;
+            lbase[j] = mid_off + (local + halo) * CELL;
+            tmask[j] = P0 + local < p.total ? peb[j][0] : 0;
+        }
+        f32x4 acc[JTB][MT];
+        pair_kloop<NB, MT, F16, JTB>(lds, zero_off, ktab, ars_b, lane * 16, lbase, tmask, acc);
+        char* const outp = reinterpret_cast<char*>(p.out);
+#pragma unroll
+        for (int j = 0; j < JTB; ++j) {
+            if (!((tmask[j] >> 13) & 1)) continue;
+            const int local = (w * JTB + j) * 16 + pcol;
+            const int bmask = (tmask[j] >> 9) & 15;
+            const size_t ocell = (size_t)(pbb[j] * p.cpc_out + peb[j][1]) * CELL;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = m * 16 + 4 * g;
+                if (co0 >= NB * 8) continue;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(lds + border_off + ((16 + bmask) * (NB * 8) + co0) * 4);
+                const u32x2 rw = *reinterpret_cast<const u32x2*>(lds + (local + 2 * halo) * CELL + co0 * 2);   // x_{i-1} at this position
+                f32x4 rv;
+                if (F16) {
+                    rv[0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[0] & 0xffffu));
+                    rv[1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[0] >> 16));
+                    rv[2] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[1] & 0xffffu));
+                    rv[3] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[1] >> 16));
+                } else {
+                    const unsigned a = rw[0], b = rw[1];
+                    rv = (f32x4){lo_f(a), hi_f(a), lo_f(b), hi_f(b)};
+                }
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = relu1(fmaf(acc[j][m][r], p.inv_scale_b, bb[r])) + rv[r];
+                    v[r] = co0 + r < p.Cout ? x : 0.f;
+                    amax = fmaxf(amax, fabsf(v[r]));
+                }
+                *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
+            }
+        }
+    }
+    range_note(p.rg, amax);
+}
+
+size_t conv3x3_pair_lds_bytes(int cp, int Ws, int tile) {
+    return (size_t)(2 * tile + 6 * (Ws + 1) + 1) * cp * 2 + 512 + 2 * 16 * cp * 4;
+}
+// output positions per workgroup of the pair kernel for sub-maps Ws cells wide (0: not supported): 256 when the intermediate tile
+// (256 + 2 Ws + 2 cells) fits five position tiles per wave, else 192
+int conv3x3_pair_tile(int C, int Ws) {
+    const int cp = (C + 7) / 8 * 8;
+    if (cp != 48) return 0;
+    for (int tile : {256, 192})
+        if (tile + 2 * (Ws + 1) <= 320 && conv3x3_pair_lds_bytes(cp, Ws, tile) <= 80 * 1024 - 256) return tile;
+    return 0;
+}
+
+template <bool F16, int JTB>
+static hipError_t launch_pair_k(const PairConvParams& p, hipStream_t s) {
+    const unsigned grid = (unsigned)((p.total + 64 * JTB - 1) / (64 * JTB));
+    const size_t lds = conv3x3_pair_lds_bytes(48, p.Ws, 64 * JTB);
+    auto k = conv3x3_pair_kernel<6, 3, F16, JTB>;
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_pair(const PairConvParams& p, int C, hipStream_t s) {
+    if (p.total <= 0) return hipSuccess;
+    const int tile = conv3x3_pair_tile(C, p.Ws);
+    if (!tile || (long long)p.total + 320 + 4 * p.Ws + 4 >= (1 << 24) || (long long)p.total * 96 >= (1LL << 31)) return hipErrorInvalidValue;
+    if (tile == 256) return p.f16 ? launch_pair_k<true, 4>(p, s) : launch_pair_k<false, 4>(p, s);
+    return p.f16 ? launch_pair_k<true, 3>(p, s) : launch_pair_k<false, 3>(p, s);
+}
+
 // ------------------------------------------------------------------------------------------------ fp32 NCHW -> CL
 // (B, C, H, W) fp32 -> pooled (window kh x kw, stride = window, floor; mode 0 average, 1 max; 1 x 1 = plain transpose)
 // channels-last (B, H/kh, W/kw, cp) fp32, i.e. layout(1).  One thread: one output position x four channels.

@@ -132,6 +132,7 @@ struct kws_handle {
     // workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    bool t3_pair = true;                   // tiled plan, 16-bit tensors: consecutive layers of equal dilation in one kernel (KWS_T3_PAIR=0: off)
     DevMem range_flag;                     // device words: [0] fp16 range guard of the layer-wise plans (kws_internal.h), [16] /
                                            // [32] clip / unit counters of the fused res8 and front-end kernels
 
@@ -681,6 +682,40 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                 const int ld_out = i < d.n_layers ? ilog2(resnet_dilation(d, i + 1)) : 0;
                 const int dd = 1 << ld_in;
                 const bool even = (i % 2) == 0;
+                // odd i and i + 1 with the same dilation, 16-bit tensors: one kernel for both (y_i never leaves the CU)
+                if (!even && m_terms == 1 && h->t3_pair && i + 1 <= d.n_layers && resnet_dilation(d, i + 1) == dd &&
+                    conv3x3_pair_tile(C, (sh.W + dd - 1) / dd) > 0) {
+                    const int ld_out2 = i + 1 < d.n_layers ? ilog2(resnet_dilation(d, i + 2)) : 0;
+                    std::unique_ptr<ConvLayer::PosTab>& pt2 = h->rconv[i + 1].postabs[T];
+                    if (!pt2) {
+                        std::vector<int> tab;
+                        std::unique_ptr<ConvLayer::PosTab> fresh(new ConvLayer::PosTab);
+                        build_tile_conv_table(sh.H, sh.W, ld_in, ld_out2, ld_x, tab, fresh->cpc[0], fresh->cpc[1], fresh->cpc[2]);
+                        if ((rc = fresh->mem.upload(tab.data(), tab.size() * sizeof(int)))) { h->rconv[i + 1].postabs.erase(T); return rc; }
+                        pt2 = std::move(fresh);
+                    }
+                    PairConvParams pp{};
+                    pp.in = xc; pp.out = xn;
+                    pp.f16 = m_f16;
+                    pp.apk_a = m_f16 ? h->rconv[i].apk_t3h.as<unsigned short>() : h->rconv[i].apk16.as<unsigned short>();
+                    pp.apk_b = m_f16 ? h->rconv[i + 1].apk_t3h.as<unsigned short>() : h->rconv[i + 1].apk16.as<unsigned short>();
+                    pp.inv_scale_a = m_f16 ? 1.0f / h->rconv[i].t3h_scale : 1.0f;
+                    pp.inv_scale_b = m_f16 ? 1.0f / h->rconv[i + 1].t3h_scale : 1.0f;
+                    pp.border_a = h->rconv[i].has_border ? h->rconv[i].border_pad.as<float>() : nullptr;
+                    pp.border_b = h->rconv[i + 1].has_border ? h->rconv[i + 1].border_pad.as<float>() : nullptr;
+                    pp.B = nb; pp.H = sh.H; pp.W = sh.W; pp.Cout = C;
+                    pp.ld = ld_in; pp.ld_out = ld_out2;
+                    pp.Hs = (sh.H + dd - 1) / dd; pp.Ws = (sh.W + dd - 1) / dd;
+                    pp.total = nb * dd * dd * pp.Hs * pp.Ws;
+                    pp.rg = rg;
+                    pp.postab = pt2->mem.as<int>();
+                    pp.cpc_in = pt2->cpc[0]; pp.cpc_out = pt2->cpc[1];
+                    HIP_TRY(launch_conv3x3_pair(pp, C, s));
+                    std::swap(xc, xn);
+                    ld_x = ld_out2;
+                    ++i;
+                    continue;
+                }
                 TileConvParams tp{};
                 tp.in = even ? Y : xc;
                 tp.out = even ? xn : Y;
@@ -1048,6 +1083,7 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
         if (std::strcmp(lw, "fp32") == 0) h->lw_mode = LW_FP32;
         else if (std::strcmp(lw, "nchw") == 0) h->lw_mode = LW_NCHW;
     }
+    if (const char* tp = std::getenv("KWS_T3_PAIR")) h->t3_pair = std::atoi(tp) != 0;   // A/B and tests: 0 = one kernel per layer
     int rc = setup_frontend(h.get());
     if (rc) return rc;
     const unsigned zero_word[64] = {0};

@@ -321,6 +321,25 @@ bool conv3x3_tile_supported(int C, int Cout, int Ws);
 void build_tile_conv_table(int H, int W, int ld_in, int ld_out, int ld_res, std::vector<int>& tab, int& cpc_in, int& cpc_out, int& cpc_res);
 void pack_conv3x3_tile_weights_f16(int C, const float* w /*C,C,3,3*/, float scale, std::vector<unsigned short>& dst);
 hipError_t launch_conv3x3_tile(const TileConvParams& p, int C, hipStream_t s);
+// Two consecutive layers of equal dilation (odd i, i + 1) in one kernel, 16-bit tensors only (conv3x3_tile.hip)
+struct PairConvParams {
+    const void* in;        // x_{i-1}, CL 16-bit tensor in layout(2^ld): conv_i's input AND conv_{i+1}'s residual
+    void* out;             // x_{i+1}, written in layout(2^ld_out)
+    const unsigned short* apk_a;   // conv_i / conv_{i+1} weights in the fragment order of the single-layer kernel
+    const unsigned short* apk_b;
+    const float* border_a; // (16, C padded to 8) border-bias tables, or nullptr
+    const float* border_b;
+    int B, H, W, Cout;
+    int ld, ld_out;
+    int Hs, Ws, total;     // sub-map size and cells of the input layout (as TileConvParams)
+    int f16;               // operand / tensor type: fp16 (1) or bf16 (0)
+    float inv_scale_a, inv_scale_b;   // 2^-S of the fp16 weights (1 for bf16)
+    RangeGate rg;
+    const int* postab;     // conv_{i+1}'s per-cell table (build_tile_conv_table): both layers share the input layout
+    int cpc_in, cpc_out;
+};
+int conv3x3_pair_tile(int C, int Ws);   // output positions per workgroup, 0 = geometry not supported
+hipError_t launch_conv3x3_pair(const PairConvParams& p, int C, hipStream_t s);
 // First conv of the cnn-* models from an LDS image of the clip (conv_in1.hip): Cin == 1, kw == 8, no padding, fused MaxPool
 struct In1ConvParams {
     const float* feat;     // (B, T, F) fp32 feature maps

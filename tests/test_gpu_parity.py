@@ -460,6 +460,34 @@ def test_layerwise_fp16_range_guard(torch_cuda, case):
     assert torch.equal(model(x[:n_clean]), torch.from_numpy(got[:n_clean]).cuda())     # the clean chunk kept its fp16 pass
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ["res15", "res26", "hey_snips"])
+def test_layer_pairs_in_one_kernel_are_bit_identical(torch_cuda, dtype, case, monkeypatch):
+    """16-bit tensors on the tiled plan: an odd layer and the even layer behind it run in ONE kernel when they share a dilation
+    (conv_i's output stays in LDS, x_{i-1} serves as input and residual from the same staged tile; reference model/resnet.py:46-55).
+    The intermediate map is rounded exactly as the store it replaces, so the logits must equal the one-kernel-per-layer form bit for
+    bit -- on res15 (pairs at dilations 1, 2, 4, 8), res26 (pooled map, every pair) and the 901-frame hey_snips model (dilations to 128,
+    partial sub-maps), over a batch that spans several workgroups and a chunk boundary."""
+    torch = torch_cuda
+    from oracle import weights
+    if case == "res15":
+        cfg, n, t = {"n_feature_maps": 45, "n_layers": 13, "use_dilation": True, "n_labels": 12}, 1100, 101
+    elif case == "res26":
+        cfg, n, t = {"n_feature_maps": 45, "n_layers": 24, "use_dilation": False, "pool": [2, 2], "n_labels": 12}, 300, 101
+    else:
+        cfg, n, t = {"n_feature_maps": 45, "n_layers": 24, "use_dilation": True, "n_labels": 2}, 9, 901
+    sd = weights.make_state_dict("ResNet", cfg, seed=11)
+    x = torch.from_numpy(weights.make_features(n, seed=12, time=t)).cuda()
+    monkeypatch.setenv("KWS_T3_PAIR", "1")
+    fused = _build(torch, "ResNet", dict(cfg, dtype=dtype), sd)
+    got = fused(x)
+    assert fused.plan_name() == "resnet_tiled"
+    monkeypatch.setenv("KWS_T3_PAIR", "0")
+    plain = _build(torch, "ResNet", dict(cfg, dtype=dtype), sd)
+    want = plain(x)
+    assert torch.isfinite(got).all() and torch.equal(got, want), float((got - want).abs().max())
+
+
 def test_fused_res8_takes_any_fp32_feature_range(torch_cuda):
     """The reference's ResNet.forward takes any finite fp32 feature (model/resnet.py:39-41); the fused res8 kernel stages features
     as fp16 pairs.  kws_forward therefore measures every clip's feature range on the device and the kernel stages out-of-range
