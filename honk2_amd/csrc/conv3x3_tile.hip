@@ -35,6 +35,8 @@
 // conv0_cl_kernel (conv_0 + ReLU [+ AvgPool] straight into a CL tensor) and mean_linear_cl_kernel (the tail) live here too.
 #include "kws_internal.h"
 
+#include <cstdlib>
+
 namespace kws {
 
 namespace {
@@ -531,10 +533,15 @@ void build_tile_conv_table(int H, int W, int ld_in, int ld_out, int ld_res, std:
 // is read from the staged tile, not from memory.  Per pair: read 1.5 - 1.9 x + write 1 x instead of (1.26 + 1) + (1.26 + 1 + 1) tensor
 // passes, one launch instead of two; the halo row of y_i is computed twice (the matrix pipe has the room).
 // JTB: output position tiles per wave (TILE = 64 JTB positions); a wave takes up to 5 tiles of the intermediate map (<= 320 cells).
-struct PairKStep { int off, tap; };
+template <int MT, bool F16>
+__device__ __forceinline__ void pair_first_frags(const __amdgpu_buffer_rsrc_t ars, int avoff, u32x4 (&a)[MT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff, (m * (F16 ? 2 : 3)) * 1024, 0));
+}
 template <int NB, int MT, bool F16, int JT>
 __device__ __forceinline__ void pair_kloop(const char* lds, const int zero_off, const int2_* ktab, const __amdgpu_buffer_rsrc_t ars,
-                                           const int avoff, const int (&lbase)[JT], const int (&tmask)[JT], f32x4 (&acc)[JT][MT]) {
+                                           const int avoff, const u32x4 (&a_first)[MT], const int (&lbase)[JT], const int (&tmask)[JT],
+                                           f32x4 (&acc)[JT][MT]) {
     constexpr int WP = F16 ? 2 : 3;                 // parts per weight fragment group as packed on the host (part 0 is used)
     constexpr int STEPS = (9 * NB + 3) / 4;
     auto b_addr = [&](int j, int2_ e) {
@@ -548,7 +555,8 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int zero_off, 
     };
     u32x4 a[2][MT], bb[2];
     int2_ e_c = ktab[0];
-    load_a(a[0], 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[0][m] = a_first[m];   // k-step 0's fragments: requested by the caller ahead of its barrier
     bb[0] = *reinterpret_cast<const u32x4*>(lds + b_addr(0, e_c));
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
@@ -576,12 +584,15 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int zero_off, 
     }
 }
 
-template <int NB, int MT, bool F16, int JTB>
-__global__ __launch_bounds__(256, 2) void conv3x3_pair_kernel(PairConvParams p) {
+// NW: waves per workgroup (4 or 8).  Eight waves share one tile's LDS image: twice the waves per CU for the same bytes of LDS -- the
+// fused kernel is a chain of dependent phases (stage, conv_i, barrier, conv_{i+1}, store) and was bound by occupancy, not by bytes.
+template <int NB, int MT, bool F16, int JTB, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_pair_kernel(PairConvParams p) {   // two workgroups per CU
     constexpr int CELL = NB * 16;                   // one 16-bit part: LDS cell = global cell
     constexpr int STEPS = (9 * NB + 3) / 4;
-    constexpr int TILE_P = 64 * JTB, JTA = 5;
-    constexpr int NQ = NB, NGRP = 256 / NQ;
+    constexpr int NT = 64 * NW;
+    constexpr int TILE_P = 16 * NW * JTB, JTA = NW == 8 ? 3 : 5;
+    constexpr int NQ = NB, NGRP = NT / NQ;
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
     const int tid = threadIdx.x;
@@ -628,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pair_kernel(PairConvParams p) 
             const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
             reinterpret_cast<int2_*>(lds + zero_off + CELL)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16 - zero_off, tap < 9 ? tap : 31};
         }
-        for (int t = tid; t < 2 * 32 * NB; t += 256) {
+        for (int t = tid; t < 2 * 32 * NB; t += NT) {
             const int which = t / (32 * NB), r = t - which * 32 * NB;
             const float* src = which ? p.border_b : p.border_a;
             f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pair_kernel(PairConvParams p) 
         }
         if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
-            constexpr int UNR = 10;   // (TILE_P + 4 halo) / 42 cells per pass: all of a thread's loads in flight together
+            constexpr int UNR = NW == 8 ? 6 : 10;   // (TILE_P + 4 halo) / NGRP cells per pass: all of a thread's loads in flight together
             for (int i0 = grp; i0 < n_in; i0 += UNR * NGRP) {
                 f32x4 v[UNR];
 #pragma unroll
@@ -653,10 +664,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pair_kernel(PairConvParams p) 
             }
         }
     }
-    __syncthreads();
-
     const __amdgpu_buffer_rsrc_t ars_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk_a), 0, STEPS * MT * (F16 ? 2 : 3) * 1024, 0x00020000);
     const __amdgpu_buffer_rsrc_t ars_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk_b), 0, STEPS * MT * (F16 ? 2 : 3) * 1024, 0x00020000);
+    u32x4 afirst[MT];
+    pair_first_frags<MT, F16>(ars_a, lane * 16, afirst);   // in flight across the barrier
+    __syncthreads();
+
     const int2_* const ktab = reinterpret_cast<const int2_*>(lds + zero_off + CELL) + g;
     float amax = 0.f;
     // ---------------------------------------------------------------- conv_i on the intermediate cells -> LDS
@@ -670,7 +683,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pair_kernel(PairConvParams p) 
             tmask[j] = (lm < n_mid && Pm >= 0 && Pm < p.total) ? pea[j] : 0;   // outside: no live tap, never read by conv_b either
         }
         f32x4 acc[JTA][MT];
-        pair_kloop<NB, MT, F16, JTA>(lds, zero_off, ktab, ars_a, lane * 16, lbase, tmask, acc);
+        pair_kloop<NB, MT, F16, JTA>(lds, zero_off, ktab, ars_a, lane * 16, afirst, lbase, tmask, acc);
+        pair_first_frags<MT, F16>(ars_b, lane * 16, afirst);   // conv_{i+1}'s first fragments: in flight across the epilogue and the barrier
 #pragma unroll
         for (int j = 0; j < JTA; ++j) {
             const int lm = (w * JTA + j) * 16 + pcol;
@@ -703,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pair_kernel(PairConvParams p) 
             tmask[j] = P0 + local < p.total ? peb[j][0] : 0;
         }
         f32x4 acc[JTB][MT];
-        pair_kloop<NB, MT, F16, JTB>(lds, zero_off, ktab, ars_b, lane * 16, lbase, tmask, acc);
+        pair_kloop<NB, MT, F16, JTB>(lds, zero_off, ktab, ars_b, lane * 16, afirst, lbase, tmask, acc);
         char* const outp = reinterpret_cast<char*>(p.out);
 #pragma unroll
         for (int j = 0; j < JTB; ++j) {
@@ -744,36 +758,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pair_kernel(PairConvParams p) 
 size_t conv3x3_pair_lds_bytes(int cp, int Ws, int tile) {
     return (size_t)(2 * tile + 6 * (Ws + 1) + 1) * cp * 2 + 512 + 2 * 16 * cp * 4;
 }
-// output positions per workgroup of the pair kernel for sub-maps Ws cells wide (0: not supported): 256 when the intermediate tile
-// (256 + 2 Ws + 2 cells) fits five position tiles per wave, else 192
+// output positions per workgroup of the pair kernel for sub-maps Ws cells wide (0: not supported): 256 (eight waves, three
+// intermediate tiles each: 256 + 2 Ws + 2 <= 384 cells); the four-wave form takes 256 or 192
 int conv3x3_pair_tile(int C, int Ws) {
     const int cp = (C + 7) / 8 * 8;
     if (cp != 48) return 0;
-    for (int tile : {256, 192})
-        if (tile + 2 * (Ws + 1) <= 320 && conv3x3_pair_lds_bytes(cp, Ws, tile) <= 80 * 1024 - 256) return tile;
-    return 0;
+    return (256 + 2 * (Ws + 1) <= 384 && conv3x3_pair_lds_bytes(cp, Ws, 256) <= 80 * 1024 - 256) ? 256 : 0;
 }
 
-template <bool F16, int JTB>
+template <bool F16, int JTB, int NW>
 static hipError_t launch_pair_k(const PairConvParams& p, hipStream_t s) {
-    const unsigned grid = (unsigned)((p.total + 64 * JTB - 1) / (64 * JTB));
-    const size_t lds = conv3x3_pair_lds_bytes(48, p.Ws, 64 * JTB);
-    auto k = conv3x3_pair_kernel<6, 3, F16, JTB>;
+    constexpr int tile = 16 * NW * JTB;
+    const unsigned grid = (unsigned)((p.total + tile - 1) / tile);
+    const size_t lds = conv3x3_pair_lds_bytes(48, p.Ws, tile);
+    auto k = conv3x3_pair_kernel<6, 3, F16, JTB, NW>;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), lds, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_pair(const PairConvParams& p, int C, hipStream_t s) {
     if (p.total <= 0) return hipSuccess;
     const int tile = conv3x3_pair_tile(C, p.Ws);
-    if (!tile || (long long)p.total + 320 + 4 * p.Ws + 4 >= (1 << 24) || (long long)p.total * 96 >= (1LL << 31)) return hipErrorInvalidValue;
-    if (tile == 256) return p.f16 ? launch_pair_k<true, 4>(p, s) : launch_pair_k<false, 4>(p, s);
-    return p.f16 ? launch_pair_k<true, 3>(p, s) : launch_pair_k<false, 3>(p, s);
+    if (!tile || (long long)p.total + 384 + 4 * p.Ws + 4 >= (1 << 24) || (long long)p.total * 96 >= (1LL << 31)) return hipErrorInvalidValue;
+    static const int nw_env = std::getenv("KWS_T3_PAIR_NW") ? std::atoi(std::getenv("KWS_T3_PAIR_NW")) : 4;   // A/B knob (8 waves: measured slower, 16.5 against 15.7 ms for res15 bf16)
+    if (nw_env != 4) return p.f16 ? launch_pair_k<true, 2, 8>(p, s) : launch_pair_k<false, 2, 8>(p, s);          // 256 positions, eight waves
+    if (256 + 2 * (p.Ws + 1) <= 320) return p.f16 ? launch_pair_k<true, 4, 4>(p, s) : launch_pair_k<false, 4, 4>(p, s);
+    return p.f16 ? launch_pair_k<true, 3, 4>(p, s) : launch_pair_k<false, 3, 4>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------ fp32 NCHW -> CL
