@@ -1077,6 +1077,8 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
     h->d = *desc;
     HIP_TRY(hipGetDevice(&h->device));
     HIP_TRY(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+    if (const char* nc = std::getenv("KWS_N_CU"))   // experiments with CU-masked streams: size the persistent grids for fewer CUs
+        if (std::atoi(nc) > 0 && std::atoi(nc) < h->n_cu) h->n_cu = std::atoi(nc);
     const char* fl = std::getenv("KWS_FORCE_LAYERWISE");
     h->force_layerwise = fl && fl[0] == '1';
     if (const char* lw = std::getenv("KWS_LAYERWISE_IMPL")) {

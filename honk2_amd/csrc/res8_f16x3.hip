@@ -273,11 +273,12 @@ __device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag&
 
 // One conv_i + epilogue (i = layer + 1).  `fa0` arrives holding k-step 0's weight fragments (requested before the previous
 // epilogue and its barriers) and leaves holding the next layer's.
-template <int TERMS>
+template <int TERMS, bool EVEN>
 __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_buffer_rsrc_t ars, int& avoff, const int (&om)[3],
                                         const int layer, f32x4 (&acc)[5][3], f32x4& accx, f32x4 (&prev)[5][3], f32x4& prevx,
                                         int& shift, AFrags (&fa)[2] R8H_TSARG) {
-    const bool even = layer & 1, last = layer == R8_LAYERS - 1;   // reference layer i = layer + 1: residual on even i
+    constexpr bool even = EVEN;                  // reference layer i = layer + 1: residual on even i (odd `layer`)
+    const bool last = layer == R8_LAYERS - 1;
     const int g = c.g;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
     constexpr int NB = R8H_BDEPTH + 1;
@@ -391,13 +392,17 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
             }
         }
     }
+    {   // two values per v_max3_f32, three independent chains (one per slot) instead of one of 32 dependent instructions
+        float am[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+        for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {   // two values per v_max3_f32
-            amax = fmaxf(fmaxf(amax, fabsf(acc[j][m][0])), fabsf(acc[j][m][1]));
-            amax = fmaxf(fmaxf(amax, fabsf(acc[j][m][2])), fabsf(acc[j][m][3]));
-        }
+            for (int m = 0; m < 3; ++m) {
+                am[m] = fmaxf(fmaxf(am[m], fabsf(acc[j][m][0])), fabsf(acc[j][m][1]));
+                am[m] = fmaxf(fmaxf(am[m], fabsf(acc[j][m][2])), fabsf(acc[j][m][3]));
+            }
+        amax = fmaxf(fmaxf(am[0], am[1]), am[2]);
+    }
     if (c.xvalid) {
         amax = fmaxf(fmaxf(amax, fabsf(accx[0])), fabsf(accx[1]));
         amax = fmaxf(fmaxf(amax, fabsf(accx[2])), fabsf(accx[3]));
@@ -785,13 +790,19 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 
         R8H_TS(3)
         f32x4 acc[5][3], accx;
-#pragma unroll 1   // one copy of the layer's code: the six inlined copies of round 2 made the kernel 66 KB, more than the instruction cache
-        for (int layer = 0; layer < R8_LAYERS; ++layer) {
-            x_layer<TERMS>(p, c, ars, avoff, om, layer, acc, accx, prev, prevx, shift, fa R8H_TSPASS);
+        // Two copies of the layer's code (odd / even i: the residual path is compile-time, a runtime flag cost selects and register
+        // copies on every value), walked three times: the six inlined copies of round 2 made the kernel 66 KB, more than the
+        // instruction cache.
+#pragma unroll 1
+        for (int lp = 0; lp < R8_LAYERS / 2; ++lp) {
+            x_layer<TERMS, false>(p, c, ars, avoff, om, 2 * lp, acc, accx, prev, prevx, shift, fa R8H_TSPASS);
 #ifdef R8H_TIMING
-            if (layer == 0) { R8H_TS(4) }
-            else if (layer == 1) { R8H_TS(5) }
-            else if (layer == 4) { R8H_TS(6) }
+            if (lp == 0) { R8H_TS(4) }
+#endif
+            x_layer<TERMS, true>(p, c, ars, avoff, om, 2 * lp + 1, acc, accx, prev, prevx, shift, fa R8H_TSPASS);
+#ifdef R8H_TIMING
+            if (lp == 0) { R8H_TS(5) }
+            else if (lp == 1) { R8H_TS(6) }
 #endif
         }
         x_tail(p, c, pos_tab, clip, acc, accx);
