@@ -710,9 +710,12 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 #pragma unroll
                             for (int m = 0; m < 3; ++m) { MF(a0[m][0], bh, cc[m]); }
                         }
-                        s0 += relu4(cc[0]);
-                        s1 += relu4(cc[1]);
-                        s2 += relu4(cc[2]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {   // scalar adds: on f32x4 values these become v_pk_add_f32, which issues slower than two plain adds beside MFMAs
+                            s0[r] += relu1(cc[0][r]);
+                            s1[r] += relu1(cc[1][r]);
+                            s2[r] += relu1(cc[2][r]);
+                        }
                     }
                 }
                 prev[j][0] = s0 * post;
@@ -736,7 +739,8 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
                             MF(a0[0][0], bl, cx);
                             MF(a0[0][0], bh, cx);
                         }
-                        sx += relu4(cx);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sx[r] += relu1(cx[r]);
                     }
                 }
                 prevx = sx * post;
