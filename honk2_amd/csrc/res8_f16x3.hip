@@ -364,7 +364,10 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
     for (int m = 0; m < 3; ++m) {
         f32x4 sc = *reinterpret_cast<const f32x4*>(bt + 16 * c.cm[m]);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(bt + 48 + 16 * c.cm[m]);
-        if (!even) sc *= up;
+        if (!even) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] *= up;   // (scalar multiplies: no v_pk_mul_f32)
+        }
         if (even) {
 #pragma unroll
             for (int j = 0; j < 5; ++j)
@@ -756,13 +759,15 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         AFrags fa[2];
         load_a(fa[0], ars, avoff, 0, om);   // conv_1's first weight fragments
         {
-            float amax = 0.f;
+            float am[3] = {0.f, 0.f, 0.f};   // pooled ReLU outputs: >= 0.  Three independent chains of v_max3_f32, not one of 64 dependent maxima
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) amax = fmaxf(amax, prev[j][m][r]);   // pooled ReLU outputs: >= 0
+                for (int m = 0; m < 3; ++m) {
+                    am[m] = fmaxf(fmaxf(am[m], prev[j][m][0]), prev[j][m][1]);
+                    am[m] = fmaxf(fmaxf(am[m], prev[j][m][2]), prev[j][m][3]);
+                }
+            float amax = fmaxf(fmaxf(am[0], am[1]), am[2]);
             if (c.xvalid) amax = fmaxf(fmaxf(amax, prevx[0]), fmaxf(fmaxf(prevx[1], prevx[2]), prevx[3]));
             guard_push(reinterpret_cast<unsigned*>(c.red), w, lane, amax);   // group 0; layer l uses group (l + 1) & 1
         }
