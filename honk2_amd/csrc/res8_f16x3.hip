@@ -86,7 +86,6 @@ __device__ __forceinline__ float relu1(float x) {
     const int b = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
-__device__ __forceinline__ f32x4 relu4(f32x4 v) { return (f32x4){relu1(v[0]), relu1(v[1]), relu1(v[2]), relu1(v[3])}; }
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     const f16x2 v = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(unsigned, v);
