@@ -533,6 +533,9 @@ void build_tile_conv_table(int H, int W, int ld_in, int ld_out, int ld_res, std:
 // is read from the staged tile, not from memory.  Per pair: read 1.5 - 1.9 x + write 1 x instead of (1.26 + 1) + (1.26 + 1 + 1) tensor
 // passes, one launch instead of two; the halo row of y_i is computed twice (the matrix pipe has the room).
 // JTB: output position tiles per wave (TILE = 64 JTB positions); a wave takes up to 5 tiles of the intermediate map (<= 320 cells).
+#ifndef PAIR_APF
+#define PAIR_APF 3   // k-steps of weight-fragment look-ahead in the pair kernel (A/B knob)
+#endif
 template <int MT, bool F16>
 __device__ __forceinline__ void pair_first_frags(const __amdgpu_buffer_rsrc_t ars, int avoff, u32x4 (&a)[MT]) {
 #pragma unroll
@@ -553,18 +556,21 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int zero_off, 
         for (int m = 0; m < MT; ++m)
             ar[m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff, ((s * MT + m) * WP) * 1024, 0));
     };
-    u32x4 a[2][MT], bb[2];
+    // Weight fragments are requested PAIR_APF k-steps ahead: a k-step is only JT x MT MFMAs (144 - 240 clocks), far less than the L2 round
+    // trip the fragments take (two layers' weights do not stay in the CU's L1), and with one step of look-ahead every step waited for it.
+    constexpr int APF = PAIR_APF;
+    u32x4 a[APF + 1][MT], bb[2];
     int2_ e_c = ktab[0];
 #pragma unroll
     for (int m = 0; m < MT; ++m) a[0][m] = a_first[m];   // k-step 0's fragments: requested by the caller ahead of its barrier
+#pragma unroll
+    for (int u = 1; u < APF; ++u) load_a(a[u], u < STEPS ? u : STEPS - 1);
     bb[0] = *reinterpret_cast<const u32x4*>(lds + b_addr(0, e_c));
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
         int2_ e_n = e_c;
-        if (s + 1 < STEPS) {
-            e_n = ktab[4 * (s + 1)];
-            load_a(a[(s + 1) & 1], s + 1);
-        }
+        if (s + 1 < STEPS) e_n = ktab[4 * (s + 1)];
+        if (s + APF < STEPS) load_a(a[(s + APF) % (APF + 1)], s + APF);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
@@ -575,8 +581,8 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int zero_off, 
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 if (s == 0) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (F16) TMFH(a[s & 1][m], bb[t & 1], acc[j][m]);
-                else TMF(a[s & 1][m], bb[t & 1], acc[j][m]);
+                if (F16) TMFH(a[s % (APF + 1)][m], bb[t & 1], acc[j][m]);
+                else TMF(a[s % (APF + 1)][m], bb[t & 1], acc[j][m]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -584,14 +590,16 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int zero_off, 
     }
 }
 
-// NW: waves per workgroup (4 or 8).  Eight waves share one tile's LDS image: twice the waves per CU for the same bytes of LDS -- the
-// fused kernel is a chain of dependent phases (stage, conv_i, barrier, conv_{i+1}, store) and was bound by occupancy, not by bytes.
-template <int NB, int MT, bool F16, int JTB, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_pair_kernel(PairConvParams p) {   // two workgroups per CU
+// JTB: output position tiles per wave (TILE = 64 JTB positions); WGS: workgroups per CU the kernel is sized for -- 2: five intermediate tiles per wave
+// (<= 320 cells of y_i); 3: four (<= 256), for tiles + halos small enough that three images fit a CU (the fused kernel is a chain of dependent
+// phases -- stage, conv_i, barrier, conv_{i+1}, store -- and wants the occupancy more than the tile size).  (An eight-wave workgroup on the same
+// tile was measured slower: twice the weight-fragment traffic.)
+template <int NB, int MT, bool F16, int JTB, int WGS>
+__global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p) {
     constexpr int CELL = NB * 16;                   // one 16-bit part: LDS cell = global cell
     constexpr int STEPS = (9 * NB + 3) / 4;
-    constexpr int NT = 64 * NW;
-    constexpr int TILE_P = 16 * NW * JTB, JTA = NW == 8 ? 3 : 5;
+    constexpr int NT = 256;
+    constexpr int TILE_P = 64 * JTB, JTA = WGS == 3 ? 4 : 5;
     constexpr int NQ = NB, NGRP = NT / NQ;
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
@@ -648,13 +656,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_pair_kernel(
         }
         if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
-            constexpr int UNR = NW == 8 ? 6 : 10;   // (TILE_P + 4 halo) / NGRP cells per pass: all of a thread's loads in flight together
+            constexpr int UNR = 10;   // (TILE_P + 4 halo) / NGRP cells per pass: all of a thread's loads in flight together
             for (int i0 = grp; i0 < n_in; i0 += UNR * NGRP) {
                 f32x4 v[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int q = min(max(P0 - 2 * halo + i0 + u * NGRP, 0), p.total - 1);   // (cells that are never tapped: clamped, not tested)
-                    v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)q * CELL + qd * 16);
+                    v[u] = (p.debug & 2) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * CELL + qd * 16);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
@@ -683,7 +691,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_pair_kernel(
             tmask[j] = (lm < n_mid && Pm >= 0 && Pm < p.total) ? pea[j] : 0;   // outside: no live tap, never read by conv_b either
         }
         f32x4 acc[JTA][MT];
-        pair_kloop<NB, MT, F16, JTA>(lds, zero_off, ktab, ars_a, lane * 16, afirst, lbase, tmask, acc);
+        if (p.debug & 1) {
+#pragma unroll
+            for (int j = 0; j < JTA; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else
+            pair_kloop<NB, MT, F16, JTA>(lds, zero_off, ktab, ars_a, lane * 16, afirst, lbase, tmask, acc);
         pair_first_frags<MT, F16>(ars_b, lane * 16, afirst);   // conv_{i+1}'s first fragments: in flight across the epilogue and the barrier
 #pragma unroll
         for (int j = 0; j < JTA; ++j) {
@@ -717,7 +731,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_pair_kernel(
             tmask[j] = P0 + local < p.total ? peb[j][0] : 0;
         }
         f32x4 acc[JTB][MT];
-        pair_kloop<NB, MT, F16, JTB>(lds, zero_off, ktab, ars_b, lane * 16, afirst, lbase, tmask, acc);
+        if (p.debug & 64) {
+#pragma unroll
+            for (int j = 0; j < JTB; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else
+            pair_kloop<NB, MT, F16, JTB>(lds, zero_off, ktab, ars_b, lane * 16, afirst, lbase, tmask, acc);
         char* const outp = reinterpret_cast<char*>(p.out);
 #pragma unroll
         for (int j = 0; j < JTB; ++j) {
@@ -748,7 +768,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_pair_kernel(
                     v[r] = co0 + r < p.Cout ? x : 0.f;
                     amax = fmaxf(amax, fabsf(v[r]));
                 }
-                *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
+                if (!(p.debug & 4)) *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
             }
         }
     }
@@ -758,26 +778,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_pair_kernel(
 size_t conv3x3_pair_lds_bytes(int cp, int Ws, int tile) {
     return (size_t)(2 * tile + 6 * (Ws + 1) + 1) * cp * 2 + 512 + 2 * 16 * cp * 4;
 }
-// output positions per workgroup of the pair kernel for sub-maps Ws cells wide (0: not supported): 256 (eight waves, three
-// intermediate tiles each: 256 + 2 Ws + 2 <= 384 cells); the four-wave form takes 256 or 192
+// is the pair kernel available for sub-maps Ws cells wide?  (returns the largest tile it would use, 0 = no)
 int conv3x3_pair_tile(int C, int Ws) {
     const int cp = (C + 7) / 8 * 8;
     if (cp != 48) return 0;
-    return (256 + 2 * (Ws + 1) <= 384 && conv3x3_pair_lds_bytes(cp, Ws, 256) <= 80 * 1024 - 256) ? 256 : 0;
+    if (256 + 2 * (Ws + 1) <= 320 && conv3x3_pair_lds_bytes(cp, Ws, 256) <= 80 * 1024 - 256) return 256;
+    if (192 + 2 * (Ws + 1) <= 320 && conv3x3_pair_lds_bytes(cp, Ws, 192) <= 80 * 1024 - 256) return 192;
+    return 0;
 }
 
-template <bool F16, int JTB, int NW>
+template <bool F16, int JTB, int WGS>
 static hipError_t launch_pair_k(const PairConvParams& p, hipStream_t s) {
-    constexpr int tile = 16 * NW * JTB;
+    constexpr int tile = 64 * JTB;
     const unsigned grid = (unsigned)((p.total + tile - 1) / tile);
     const size_t lds = conv3x3_pair_lds_bytes(48, p.Ws, tile);
-    auto k = conv3x3_pair_kernel<6, 3, F16, JTB, NW>;
+    auto k = conv3x3_pair_kernel<6, 3, F16, JTB, WGS>;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), lds, s, p);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -785,10 +806,12 @@ hipError_t launch_conv3x3_pair(const PairConvParams& p, int C, hipStream_t s) {
     if (p.total <= 0) return hipSuccess;
     const int tile = conv3x3_pair_tile(C, p.Ws);
     if (!tile || (long long)p.total + 384 + 4 * p.Ws + 4 >= (1 << 24) || (long long)p.total * 96 >= (1LL << 31)) return hipErrorInvalidValue;
-    static const int nw_env = std::getenv("KWS_T3_PAIR_NW") ? std::atoi(std::getenv("KWS_T3_PAIR_NW")) : 4;   // A/B knob (8 waves: measured slower, 16.5 against 15.7 ms for res15 bf16)
-    if (nw_env != 4) return p.f16 ? launch_pair_k<true, 2, 8>(p, s) : launch_pair_k<false, 2, 8>(p, s);          // 256 positions, eight waves
-    if (256 + 2 * (p.Ws + 1) <= 320) return p.f16 ? launch_pair_k<true, 4, 4>(p, s) : launch_pair_k<false, 4, 4>(p, s);
-    return p.f16 ? launch_pair_k<true, 3, 4>(p, s) : launch_pair_k<false, 3, 4>(p, s);
+    static const int wgs3_env = std::getenv("KWS_T3_PAIR_WGS3") ? std::atoi(std::getenv("KWS_T3_PAIR_WGS3")) : 1;   // A/B knob
+    // three workgroups per CU on 192-position tiles when three images fit (53 KB each) and y_i's tile fits four tiles per wave
+    if (wgs3_env && 192 + 2 * (p.Ws + 1) <= 256 && conv3x3_pair_lds_bytes(48, p.Ws, 192) <= 53 * 1024)
+        return p.f16 ? launch_pair_k<true, 3, 3>(p, s) : launch_pair_k<false, 3, 3>(p, s);
+    if (tile == 256) return p.f16 ? launch_pair_k<true, 4, 2>(p, s) : launch_pair_k<false, 4, 2>(p, s);
+    return p.f16 ? launch_pair_k<true, 3, 2>(p, s) : launch_pair_k<false, 3, 2>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------ fp32 NCHW -> CL

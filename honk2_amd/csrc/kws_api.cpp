@@ -710,6 +710,8 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                     pp.rg = rg;
                     pp.postab = pt2->mem.as<int>();
                     pp.cpc_in = pt2->cpc[0]; pp.cpc_out = pt2->cpc[1];
+                    static const int pair_dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
+                    pp.debug = pair_dbg;
                     HIP_TRY(launch_conv3x3_pair(pp, C, s));
                     std::swap(xc, xn);
                     ld_x = ld_out2;

@@ -337,6 +337,7 @@ struct PairConvParams {
     RangeGate rg;
     const int* postab;     // conv_{i+1}'s per-cell table (build_tile_conv_table): both layers share the input layout
     int cpc_in, cpc_out;
+    int debug;             // KWS_T3_DEBUG, timing experiments only (results are wrong when set): 1 skip conv_i's k-loop, 64 skip conv_{i+1}'s, 2 skip the staging loads, 4 skip the output stores
 };
 int conv3x3_pair_tile(int C, int Ws);   // output positions per workgroup, 0 = geometry not supported
 hipError_t launch_conv3x3_pair(const PairConvParams& p, int C, hipStream_t s);
