@@ -35,7 +35,7 @@ B_BUILT = 96368                # what kws_forward_wav's two kernels move: + the 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input matrix (= fp32 vector) peak
 PEAK_BF16_MFMA_TFLOPS = 2516.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (spec); 2.0 PF sustained on this box (tools/coexec_probe_bf16)
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARIES = ("profiles/r02/final_summary.json", "profiles/r01/v8_summary.json")   # newest first
+PMC_SUMMARIES = ("profiles/r03/final_summary.json", "profiles/r03/v11_summary.json", "profiles/r02/final_summary.json")   # newest first
 
 
 SYNTH_BLOCK = 1024
@@ -138,10 +138,16 @@ def cpu_baseline(torch, wav_sample, sd, budget_s=12.0):
 
 def spread_indices(total, count):
     """`count` clip indices spread evenly over [0, total), ordered so that every prefix is itself spread over the whole range
-    (the CPU leg evaluates a time-bounded prefix): index k of the even grid is visited in the order k * 7919 mod count."""
+    (the CPU leg evaluates a time-bounded prefix): the even grid is visited in bit-reversed order (van der Corput), so a prefix
+    of 2^k entries is an even grid of its own and any other prefix lies between two such grids."""
     import numpy as np
     grid = (np.arange(count, dtype=np.int64) * total) // count
-    order = (np.arange(count, dtype=np.int64) * 7919) % count
+    bits = max(1, int(count - 1).bit_length())
+    k = np.arange(1 << bits, dtype=np.int64)
+    rev = np.zeros_like(k)
+    for b in range(bits):
+        rev |= ((k >> b) & 1) << (bits - 1 - b)
+    order = rev[rev < count]
     return grid[order]
 
 

@@ -239,3 +239,23 @@ def test_data_parallel_replicas_get_one_engine_per_device_and_never_close_each_o
     with torch.no_grad():
         next(model.parameters()).add_(1.0)                  # a new version -> re-upload, on that device's engine only
     assert model.engine() is e0 and e0.loaded == 2 * n and e1.loaded == n
+
+
+def test_bench_parity_sample_is_spread_in_every_prefix():
+    """bench.py's CPU leg evaluates a time-bounded PREFIX of its sample: every prefix has to straddle the whole batch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    idx = bench.spread_indices(65536, 16384)
+    assert len(np.unique(idx)) == 16384 and idx.min() == 0 and idx.max() == 65532
+    for n in (256, 1024, 8192, 13056):
+        pre = np.sort(idx[:n])
+        assert pre[0] < 65536 // 8 and pre[-1] > 65536 - 65536 // 8          # reaches both ends
+        assert np.diff(pre).max() <= 2 * 65536 // (1 << (n.bit_length() - 1))   # no hole wider than two steps of the largest even grid inside the prefix
+    lo, hi = [], []
+    from honk2_amd import dist_utils
+    for r in range(8):
+        a, b = dist_utils.shard_bounds(65536, r, 8)
+        lo.append(a); hi.append(b)
+    assert lo[0] == 0 and hi[-1] == 65536 and all(b - a == 8192 for a, b in zip(lo, hi))   # the shard record's 8 192 clips
