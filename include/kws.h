@@ -132,7 +132,9 @@ int kws_mfcc(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_f
 int kws_mfcc_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise, float noise_pct, int B, int n_samples,
                    float* d_feat, void* stream);
 
-/* feat (B, T, freq) fp32 -> logits (B, n_labels) fp32. */
+/* feat (B, T, freq) fp32 -> logits (B, n_labels) fp32.  Features may be any finite fp32 values (reference model/resnet.py:39-41,
+ * model/cnn.py:79-81); needs kws_workspace_bytes(h, B, T) of workspace on every plan (the fused res8 plan keeps 4 bytes per clip
+ * there: the power of two an out-of-range clip's features are staged down by). */
 int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits, void* stream);
 
 /* wav (B, n_samples) fp32 -> logits (B, n_labels) fp32 (feature maps stay in the workspace). */
