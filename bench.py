@@ -367,6 +367,18 @@ def main():
     lbufs = [logits, torch.empty_like(logits)] if overlap else [logits]
     gbufs = [gathered, torch.empty_like(gathered)] if overlap else [gathered]
     coll_stream = torch.cuda.Stream(device) if overlap else None
+    if overlap and not self_gather:
+        # One collective on the side stream before anything is timed: if this build of torch / RCCL refuses the pattern (an
+        # exception every rank sees alike), fall back to the gather on the compute stream instead of losing the run.
+        try:
+            with torch.cuda.stream(coll_stream):
+                dist.all_gather_into_tensor(gbufs[1], lbufs[1])
+            torch.cuda.synchronize()
+        except Exception as exc:   # noqa: BLE001
+            if rank == 0:
+                print(f"bench: overlapped all-gather unavailable ({exc!r}); gathering on the compute stream", file=sys.stderr)
+            overlap = False
+            lbufs, gbufs, coll_stream = [logits], [gathered], None
     coll_done = [None, None]
     state = {"i": 0}
 
