@@ -4,6 +4,7 @@
 tag=${1:-v9}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/prof_$tag
+rm -rf $out ${out}_res15_bf16 ${out}_cnn_fp16 ${out}_res15_f32   # (gpurun_out/ survives between rounds: never mix in an older run's files)
 mkdir -p $out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-shard --no-h2d > $out.stats.log 2>&1 || { echo stats failed; tail -3 $out.stats.log; exit 1; }
 n=1
