@@ -109,6 +109,7 @@ struct kws_handle {
     std::vector<float> r8_apk_host;
     std::vector<unsigned short> r8x_apk_host, r8h_apk_host;
     float r8h_scale[R8_LAYERS] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // 2^S per layer (fp16 path)
+    float r8h_kappa[R8_LAYERS] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // value of the constant channel in the map each layer writes
     // fused res8 kernel: 0 = fp16 three-term products (default), 1 = bf16 six-term (KWS_RES8_IMPL=bf16x6; also what the
     // reduced-precision dtypes use), 2 = fp32-input MFMA (KWS_RES8_IMPL=fp32)
     int res8_impl = 0;
@@ -496,10 +497,42 @@ int finalize(kws_handle* h) {
             if ((rc = h->r8_bn.upload(tab.data(), tab.size() * 4))) return rc;
             if ((rc = h->r8_apk.upload(h->r8_apk_host.data(), h->r8_apk_host.size() * 4))) return rc;
             if ((rc = h->r8x_apk.upload(h->r8x_apk_host.data(), h->r8x_apk_host.size() * 2))) return rc;
+            // res8h_kernel: BatchNorm i - 1 is folded into conv_i (i >= 2).  Its scale goes into the weights; its shift rides on a
+            // constant input channel (slot 45 of the 48-channel cells: kappa inside the map, 0 in the halo -- so the reference's zero
+            // padding AFTER BatchNorm comes out by itself): w46[co][45][tap] = sum_ci W[co][ci][tap] shift[ci].  The map behind an
+            // odd layer holds relu(acc) as it comes (true value x mu, mu = the layer's weight scale 2^S), behind an even layer the
+            // residual stream x (mu = 1); 1 / mu goes into the next layer's weights and kappa = mu.  Only the last BatchNorm is left
+            // for the tail (45 values per clip).
+            {
+                double mu_prev = 1.0;   // scale of the map conv_i reads (x_0: 1)
+                std::vector<float> w46((size_t)R8_C * 46 * 9);
+                for (int i = 1; i <= R8_LAYERS; ++i) {
+                    const std::vector<float>& W = h->rconv[i].w_host;
+                    const float* scp = i >= 2 ? sc.data() + (size_t)(i - 2) * C : nullptr;
+                    const float* sfp = i >= 2 ? sf.data() + (size_t)(i - 2) * C : nullptr;
+                    for (int co = 0; co < R8_C; ++co)
+                        for (int t9 = 0; t9 < 9; ++t9) {
+                            double bias = 0.0;
+                            for (int ci = 0; ci < R8_C; ++ci) {
+                                const double wv = W[((size_t)co * R8_C + ci) * 9 + t9];
+                                w46[((size_t)co * 46 + ci) * 9 + t9] = (float)(wv * (scp ? (double)scp[ci] : 1.0) / mu_prev);
+                                if (sfp) bias += wv * (double)sfp[ci];
+                            }
+                            w46[((size_t)co * 46 + 45) * 9 + t9] = (float)(bias / mu_prev);
+                        }
+                    h->r8h_scale[i - 1] = weight_scale_pow2(w46.data(), w46.size());
+                    pack_res8h_layer(w46.data(), h->r8h_scale[i - 1],
+                                     h->r8h_apk_host.data() + (size_t)(i - 1) * R8H_ASTEPS * 3 * 2 * 64 * 8);
+                    mu_prev = (i % 2 == 1) ? (double)h->r8h_scale[i - 1] : 1.0;
+                    h->r8h_kappa[i - 1] = (float)mu_prev;
+                }
+            }
             if ((rc = h->r8h_apk.upload(h->r8h_apk_host.data(), h->r8h_apk_host.size() * 2))) return rc;
-            std::vector<float> tabh = tab;   // fp16 path: odd layers (index 0, 2, 4) fold 2^-S into the BatchNorm scale
-            for (int i = 0; i < R8_LAYERS; i += 2)
-                for (int c = 0; c < 48; ++c) tabh[(size_t)i * 96 + c] /= h->r8h_scale[i];
+            std::vector<float> tabh(96, 0.f);   // the LAST BatchNorm only: scale[48], shift[48]
+            for (int c = 0; c < R8_C; ++c) {
+                tabh[c] = sc[(size_t)(R8_LAYERS - 1) * C + c];
+                tabh[48 + c] = sf[(size_t)(R8_LAYERS - 1) * C + c];
+            }
             if ((rc = h->r8h_bn.upload(tabh.data(), tabh.size() * 4))) return rc;
             std::vector<int> zc(1024);
             build_res8_zero_cells(zc.data());
@@ -1004,7 +1037,10 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 Res8hParams p{};
                 p.feat = feat; p.logits = logits; p.w0h = h->r8h_w0.p; p.inv_scale0 = 1.0f / h->r8h_scale0; p.apk2 = h->r8h_apk.p;
                 p.bn_tab = h->r8h_bn.as<float>(); p.out_w = h->out_w.as<float>(); p.out_b = h->out_b.as<float>();
-                for (int i = 0; i < R8_LAYERS; ++i) p.inv_scale[i] = 1.0f / h->r8h_scale[i];
+                for (int i = 0; i < R8_LAYERS; ++i) {
+                    p.inv_scale[i] = 1.0f / h->r8h_scale[i];
+                    p.kappa[i] = h->r8h_kappa[i];
+                }
                 p.B = B; p.T = T; p.F = h->d.freq; p.n_labels = h->d.n_labels; p.debug = dbg;
                 p.terms = h->d.dtype == KWS_DTYPE_F16 ? 1 : 3;
                 p.queue = h->range_flag.as<unsigned>() + 16;   // (word 0 of that block is the layer-wise range flag)
@@ -1146,9 +1182,7 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
                 } else {
                     pack_res8_layer(src, h->r8_apk_host.data() + (size_t)(idx - 1) * R8_GROUPS * 3 * 64 * 4);
                     pack_res8x_layer(src, h->r8x_apk_host.data() + (size_t)(idx - 1) * R8X_KSTEPS * 3 * 3 * 64 * 8);
-                    h->r8h_scale[idx - 1] = weight_scale_pow2(src, n);
-                    pack_res8h_layer(src, h->r8h_scale[idx - 1],
-                                     h->r8h_apk_host.data() + (size_t)(idx - 1) * R8H_ASTEPS * 3 * 2 * 64 * 8);
+                    // (res8h_kernel's fragments are packed in finalize(): the previous layer's BatchNorm is folded into them)
                 }
             }
         } else if (std::sscanf(name.c_str(), "layers.bn_%d.%31s", &idx, field) == 2) {

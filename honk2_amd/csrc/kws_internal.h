@@ -211,11 +211,12 @@ struct Res8hParams {
     float* logits;        // (B, n_labels)
     const void* w0h;      // conv_0 weight * 2^S0 as two fp16 parts, one 16x16x32 A fragment per channel tile (pack_res8h_conv0)
     float inv_scale0;     // 2^-S0
-    const void* apk2;     // conv_1..6 weights * 2^S split into two fp16 parts, fragment order (pack_res8h_layer)
-    const float* bn_tab;  // (6, 96): per layer scale[48], shift[48]; the scale of ODD layers carries the layer's 2^-S
+    const void* apk2;     // conv_1..6 weights (previous BatchNorm folded in) * 2^S split into two fp16 parts, fragment order (pack_res8h_layer)
+    const float* bn_tab;  // (96): the LAST BatchNorm's scale[48], shift[48] (applied to the 45 channel means in the tail)
     const float* out_w;   // (n_labels, 45)
     const float* out_b;   // (n_labels)
     float inv_scale[R8_LAYERS];   // 2^-S per layer
+    float kappa[R8_LAYERS];       // value of the constant channel (slot 45) in the map layer l writes: the scale of that map
     int B, T, F, n_labels;
     int debug;            // timing experiments only: 1 skip conv_0, 2 skip the MFMA loop
     int terms;            // 3: fp32-accurate products; 1: plain fp16 operands (KWS_DTYPE_F16)
@@ -226,7 +227,7 @@ size_t res8h_lds_bytes();
 // shift[b] = 0 while max |feat[b]| <= 2^14, else ceil(log2(max)) - 14: the fused kernel stages features as fp16 pairs
 hipError_t launch_feat_shift(const float* feat, int B, int n_per_clip, int* shift, hipStream_t s);
 hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s);
-void pack_res8h_layer(const float* w /*45x45x3x3*/, float scale, unsigned short* dst /*R8H_ASTEPS*3*2*64*8*/);
+void pack_res8h_layer(const float* w /*45 x 46 x 3x3: input channel 45 = the folded BatchNorm shift*/, float scale, unsigned short* dst /*R8H_ASTEPS*3*2*64*8*/);
 void pack_res8h_conv0(const float* w /*45x9*/, float scale, unsigned short* dst /*(3*2 + 3)*64*8*/);
 
 // ---------------------------------------------------------------- layer-wise kernels (layerwise.hip)

@@ -77,7 +77,7 @@ constexpr int FS = 41;                                // staged feature row stri
 constexpr int FEAT_BYTES = ((102 * FS * 4 + 15) / 16) * 16;
 static_assert(FEAT_BYTES <= MAP_BYTES, "the feature map is staged inside the (idle) activation map");
 constexpr int RED_OFF = MAP_BYTES;                    // fp32 words from here on
-constexpr int BNT_WORDS = R8_LAYERS * 96;
+constexpr int BNT_WORDS = 96;                       // the last BatchNorm's scale[48], shift[48] (the others are folded into the weights)
 constexpr int NEXT_OFF = RED_OFF + (4 * 48 + 48 + BNT_WORDS) * 4;   // one word: the clip this workgroup takes next
 constexpr int POS_OFF = NEXT_OFF + 16;                // the position table (336 x 2 B)
 constexpr int X_LDS_BYTES = POS_OFF + 21 * 16 * 2;
@@ -348,25 +348,18 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
     if (R8H_PRIO | R8H_EPRIO) __builtin_amdgcn_s_setprio(R8H_EPRIO);
     R8H_LTS(11)
 
-    // ---- epilogue in fp32: ReLU, residual (reference: even i), BatchNorm as one FMA.  The accumulators carry the layer's
-    //      weight scale 2^S; 2^-S rides on the residual FMA (even i) or is already folded into the BatchNorm scale of
-    //      the table (odd i).
-    int gq = 4 * g;
-    asm volatile("" : "+v"(gq));   // (the table addresses are built here, per layer, not hoisted and spilled)
-    const float* bt = c.bnt + layer * 96 + gq;
+    // ---- epilogue in fp32: ReLU and, on even i, the residual (reference model/resnet.py:46-55).  BatchNorm i is not applied here: its
+    //      scale is folded into conv_{i+1}'s weights and its shift rides on the constant channel (slot 45) of the map, which is set
+    //      below (kws_api.cpp, finalize).  Odd i: the map takes relu(acc) as it comes -- the layer's weight scale 2^S stays on it and
+    //      1 / 2^S is in the next layer's weights -- so an odd epilogue is ONE instruction per value, and half of what it stores are
+    //      exact zeros (operands that do not toggle the matrix pipe, on a kernel that runs at its power cap).  Even i: x = relu(acc)
+    //      2^-S + prev_x, stored as it is.
     const float up = shift > 0 ? ldexpf(1.f, shift) : 1.f;   // undo the range guard of the map this layer read (uniform)
     const float inv = p.inv_scale[layer] * up;
+    const float kap = p.kappa[layer];
     float amax = 0.f;
-    // (odd i: the power of two that undoes the range guard of the input map rides on the BatchNorm scale -- twelve
-    // multiplies by 1.0 in the common case instead of a select per value)
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        f32x4 sc = *reinterpret_cast<const f32x4*>(bt + 16 * c.cm[m]);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(bt + 48 + 16 * c.cm[m]);
-        if (!even) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[r] *= up;   // (scalar multiplies: no v_pk_mul_f32)
-        }
         if (even) {
 #pragma unroll
             for (int j = 0; j < 5; ++j)
@@ -374,13 +367,19 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
                 for (int r = 0; r < 4; ++r) {
                     const float v = fmaf(relu1(acc[j][m][r]), inv, prev[j][m][r]);
                     prev[j][m][r] = v;
-                    acc[j][m][r] = fmaf(v, sc[r], sh[r]);
+                    acc[j][m][r] = v;
                 }
         } else {
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[j][m][r] = fmaf(relu1(acc[j][m][r]), sc[r], sh[r]);
+                for (int r = 0; r < 4; ++r) acc[j][m][r] = relu1(acc[j][m][r]);
+            if (shift > 0) {   // (wave-uniform, never taken for trained models: the input map was stored scaled down)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[j][m][r] *= up;
+            }
         }
         if (m == 0) {   // the extra tile holds slot 0's channels
 #pragma unroll
@@ -389,9 +388,16 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
                 if (even) {
                     v = fmaf(v, inv, prevx[r]);
                     prevx[r] = v;
+                } else if (shift > 0) {
+                    v *= up;
                 }
-                accx[r] = fmaf(v, sc[r], sh[r]);
+                accx[r] = v;
             }
+        }
+        if (c.cm[m] == 2) {   // (wave-uniform) this slot holds channels 32..47: lane group 3, second row = the constant channel 45
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc[j][m][1] = g == 3 ? kap : acc[j][m][1];
+            if (m == 0) accx[1] = g == 3 ? kap : accx[1];
         }
     }
     {   // two values per v_max3_f32, three independent chains (one per slot) instead of one of 32 dependent instructions
@@ -480,8 +486,9 @@ __device__ __forceinline__ void x_tail(const Res8hParams& p, const XCtx& c0, con
         if (c.pcol == 0 && c.w < 3) c.red[c.w * 48 + 16 * c.cm[0] + 4 * g + r] += v;
     }
     __syncthreads();
-    if (c.tid < 48)
-        c.mvec[c.tid] = (c.red[c.tid] + c.red[48 + c.tid] + c.red[96 + c.tid] + c.red[144 + c.tid]) / (float)R8_NPOS;
+    if (c.tid < 48)   // mean over the positions, then the last BatchNorm (mean(BN(x)) == BN(mean(x)))
+        c.mvec[c.tid] = fmaf((c.red[c.tid] + c.red[48 + c.tid] + c.red[96 + c.tid] + c.red[144 + c.tid]) / (float)R8_NPOS, c0.bnt[c.tid],
+                             c0.bnt[48 + c.tid]);
     __syncthreads();
     if (c.tid < p.n_labels) {
         const float* wr = p.out_w + c.tid * R8_C;
@@ -779,6 +786,13 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
             *reinterpret_cast<u32x4*>(ldsb + (sub / 6) * PART_B + (sub % 6) * PLANE_B + cell * 16) = (u32x4){0u, 0u, 0u, 0u};
         }
         shift = __builtin_amdgcn_readfirstlane(range_shift(guard_read(reinterpret_cast<const unsigned*>(c.red))));
+#pragma unroll
+        for (int m = 0; m < 3; ++m)   // the constant channel (slot 45) of x_0's map: 1 (it carries conv_2's share of BatchNorm 1; conv_1's weights ignore it)
+            if (c.cm[m] == 2) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) prev[j][m][1] = g == 3 ? 1.0f : prev[j][m][1];
+                if (m == 0) prevx[1] = g == 3 ? 1.0f : prevx[1];
+            }
         if (shift > 0) {   // (wave-uniform, never taken for trained models)
             asm volatile("; range guard: scale the map down" ::: "memory");
             const float down = ldexpf(1.f, -shift);
@@ -900,7 +914,8 @@ void pack_res8h_conv0(const float* wt, float scale, unsigned short* dst) {
         }
 }
 
-// conv_i weight (45,45,3,3) times `scale` -> [k-step 14][channel tile 3][part 2][lane 64][8 fp16] in the kernel's K order
+// conv_i weight (45, 46, 3, 3) -- input channel 45 = the previous BatchNorm's shift, met by the map's constant channel -- times `scale` ->
+// [k-step 14][channel tile 3][part 2][lane 64][8 fp16] in the kernel's K order
 // (kinds A - D above): cout = 16 m + (lane & 15), lane group g = lane >> 4 holds 8 input channels of one tap.  The last
 // step's part-1 fragment carries a1 of blocks 4, 5 of tap 8 on groups 0, 1 AND on groups 2, 3 (it meets part 1 | part 2 of
 // the activations in one MFMA), its part-2 fragment a2 on groups 0, 1 and zeros on groups 2, 3.
@@ -908,7 +923,7 @@ void pack_res8h_layer(const float* wt, float scale, unsigned short* dst) {
     auto weight = [&](int co, int tap, int cblk, int j, bool low) -> unsigned short {
         float v = 0.f;
         const int ci = 8 * cblk + j;
-        if (co < R8_C && ci < R8_C) v = wt[((size_t)co * R8_C + ci) * 9 + tap] * scale;
+        if (co < R8_C && ci < R8_C + 1) v = wt[((size_t)co * (R8_C + 1) + ci) * 9 + tap] * scale;   // ci == 45: the folded BatchNorm shift
         const unsigned short h = f16_rne_host(v);
         return low ? f16_rne_host(v - f16_to_f_host(h)) : h;
     };
