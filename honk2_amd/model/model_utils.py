@@ -62,6 +62,18 @@ class BaseModel(ABC, nn.Module):
         self._engines = {}
         self._engines_lock = threading.Lock()
 
+    # engines are per-process device state: a deep copy / pickle of the module carries the tensors only and builds its own
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_engines", None)
+        state.pop("_engines_lock", None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._engines = {}
+        self._engines_lock = threading.Lock()
+
     def num_params(self):
         return sum(p.numel() for p in self.parameters())
 

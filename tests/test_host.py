@@ -259,3 +259,17 @@ def test_bench_parity_sample_is_spread_in_every_prefix():
         a, b = dist_utils.shard_bounds(65536, r, 8)
         lo.append(a); hi.append(b)
     assert lo[0] == 0 and hi[-1] == 65536 and all(b - a == 8192 for a, b in zip(lo, hi))   # the shard record's 8 192 clips
+
+
+def test_models_deepcopy_and_pickle_without_their_engines():
+    """copy.deepcopy(model) / pickle (torch.save of a whole module) carry the tensors only; the copy builds engines of its own."""
+    import copy
+    import pickle
+    cfg = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 12}
+    model = find_cls("model.ResNet")(dict(cfg)).eval()
+    model._engines[0] = ["sentinel", None]
+    for clone in (copy.deepcopy(model), pickle.loads(pickle.dumps(model))):
+        assert clone._engines == {} and clone._engines_lock is not model._engines_lock
+        assert all(torch.equal(a, b) for a, b in zip(clone.state_dict().values(), model.state_dict().values()))
+        assert not clone.training
+    assert model._engines[0][0] == "sentinel"
