@@ -358,17 +358,18 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
     const float inv = p.inv_scale[layer] * up;
     const float kap = p.kappa[layer];
     float amax = 0.f;
+    // What the map takes: odd i -- relu(acc), rewritten in place; even i -- the updated residual registers themselves (no copy: a copy
+    // cost 60 v_mov_b64 per layer).  The constant channel: odd i selects kappa into slot 45's row; even i needs nothing -- its kappa is 1,
+    // conv's row 45 is all zero weights and prev_x's row 45 was set to 1 behind conv_0, so x[45] = 0 * 2^-S + 1.
+    f32x4 (&outv)[5][3] = even ? prev : acc;
+    f32x4& outx = even ? prevx : accx;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         if (even) {
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = fmaf(relu1(acc[j][m][r]), inv, prev[j][m][r]);
-                    prev[j][m][r] = v;
-                    acc[j][m][r] = v;
-                }
+                for (int r = 0; r < 4; ++r) prev[j][m][r] = fmaf(relu1(acc[j][m][r]), inv, prev[j][m][r]);
         } else {
 #pragma unroll
             for (int j = 0; j < 5; ++j)
@@ -380,40 +381,39 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[j][m][r] *= up;
             }
+            if (c.cm[m] == 2) {   // (wave-uniform) this slot holds channels 32..47: lane group 3, second row = the constant channel 45
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc[j][m][1] = g == 3 ? kap : acc[j][m][1];
+            }
         }
         if (m == 0) {   // the extra tile holds slot 0's channels
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = relu1(accx[r]);
                 if (even) {
-                    v = fmaf(v, inv, prevx[r]);
-                    prevx[r] = v;
-                } else if (shift > 0) {
-                    v *= up;
+                    prevx[r] = fmaf(relu1(accx[r]), inv, prevx[r]);
+                } else {
+                    float v = relu1(accx[r]);
+                    if (shift > 0) v *= up;
+                    accx[r] = v;
                 }
-                accx[r] = v;
             }
-        }
-        if (c.cm[m] == 2) {   // (wave-uniform) this slot holds channels 32..47: lane group 3, second row = the constant channel 45
-#pragma unroll
-            for (int j = 0; j < 5; ++j) acc[j][m][1] = g == 3 ? kap : acc[j][m][1];
-            if (m == 0) accx[1] = g == 3 ? kap : accx[1];
+            if (!even && c.cm[0] == 2) accx[1] = g == 3 ? kap : accx[1];
         }
     }
-    {   // two values per v_max3_f32, three independent chains (one per slot) instead of one of 32 dependent instructions
+    {   // two values per v_max3_f32, three independent chains (one per slot) instead of one of 32 dependent instructions; every value is >= 0
         float am[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 5; ++j)
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                am[m] = fmaxf(fmaxf(am[m], fabsf(acc[j][m][0])), fabsf(acc[j][m][1]));
-                am[m] = fmaxf(fmaxf(am[m], fabsf(acc[j][m][2])), fabsf(acc[j][m][3]));
+                am[m] = fmaxf(fmaxf(am[m], outv[j][m][0]), outv[j][m][1]);
+                am[m] = fmaxf(fmaxf(am[m], outv[j][m][2]), outv[j][m][3]);
             }
         amax = fmaxf(fmaxf(am[0], am[1]), am[2]);
     }
     if (c.xvalid) {
-        amax = fmaxf(fmaxf(amax, fabsf(accx[0])), fabsf(accx[1]));
-        amax = fmaxf(fmaxf(amax, fabsf(accx[2])), fabsf(accx[3]));
+        amax = fmaxf(fmaxf(amax, outx[0]), outx[1]);
+        amax = fmaxf(fmaxf(amax, outx[2]), outx[3]);
     }
     unsigned* const ggrp = reinterpret_cast<unsigned*>(c.red) + 4 * ((layer + 1) & 1);   // the reduction buffer is idle until the tail
     if (!last) guard_push(ggrp, c.w, c.lane, amax);
@@ -425,18 +425,19 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
         shift = __builtin_amdgcn_readfirstlane(range_shift(guard_read(ggrp)));   // uniform
         if (shift > 0) {   // never taken for trained models: keep it a (wave-uniform) branch, not selects on every value
             asm volatile("; range guard: scale the map down" ::: "memory");
-            const float down = ldexpf(1.f, -shift);
+            const float down = ldexpf(1.f, -shift);   // (scaled copies: the residual registers keep their values)
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
-                for (int m = 0; m < 3; ++m) acc[j][m] *= down;
-            accx *= down;
+                for (int m = 0; m < 3; ++m) store_split(c.qa[j] + es[m], outv[j][m] * down);
+            if (c.xvalid) store_split(c.qa[5] + es[0], outx * down);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) store_split(c.qa[j] + es[m], outv[j][m]);
+            if (c.xvalid) store_split(c.qa[5] + es[0], outx);
         }
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-#pragma unroll
-            for (int m = 0; m < 3; ++m) store_split(c.qa[j] + es[m], acc[j][m]);
-        if (c.xvalid) store_split(c.qa[5] + es[0], accx);
         R8H_LTS(14)
         __syncthreads();
         R8H_LTS(15)
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
             else if (lp == 1) { R8H_TS(6) }
 #endif
         }
-        x_tail(p, c, pos_tab, clip, acc, accx);
+        x_tail(p, c, pos_tab, clip, prev, prevx);   // the last layer is even: its x is in the residual registers
         R8H_TS(7)
 #ifdef R8H_TIMING
         if ((threadIdx.x & 63) == 0) {      // the clip's features are dead: park the timestamps there (tools/r8_phases.py)
