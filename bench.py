@@ -35,6 +35,19 @@ B_BUILT = 96368                # what kws_forward_wav's two kernels move: + the 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input matrix (= fp32 vector) peak
 PEAK_BF16_MFMA_TFLOPS = 2516.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (spec); 2.0 PF sustained on this box (tools/coexec_probe_bf16)
 PEAK_HBM_GBS = 8000.0
+KERNEL_SOURCE = "honk2_amd/csrc/res8_f16x3.hip"
+
+
+def source_digest(rel):
+    """sha256 of a source file of this tree (tools/summarize_prof.py stores the same digest in the counter summaries)."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
 PMC_SUMMARIES = ("profiles/r03/final_summary.json", "profiles/r03/v11_summary.json", "profiles/r02/final_summary.json")   # newest first
 
 
@@ -260,16 +273,22 @@ def shard_record(torch, model, device, full_rate, full_k_ms, full_f_ms, full_cli
             "what": "wav -> logits on 8 192 clips = one GPU's shard of the 8-GPU run (BASELINE configs[3]); the RCCL all-gather of 393 KB of logits is not in it"}
 
 
-def h2d_record(torch, model, device, nclips):
+def h2d_record(torch, model, device, nclips, pcm16=False):
     """The PCIe-inclusive variant SURVEY.md 8(d) asks for beside the headline (never `value`): the waveforms start in PINNED
-    host memory; chunks of 8 192 clips are copied on a second stream while the previous chunk computes."""
+    host memory; chunks of 8 192 clips are copied on a second stream while the previous chunk computes.  `pcm16`: the clips
+    cross the bus as the 16-bit PCM they are on disk (`kws_forward_pcm16` decodes x / 32768 in the
+    front end's staging load), half the bytes per clip."""
     chunk = 8192
     nclips = nclips // chunk * chunk
     if nclips == 0:
         return None
-    host = torch.empty((nclips, 16000), dtype=torch.float32).pin_memory()
-    host.normal_(0.0, 0.1)
-    bufs = [torch.empty((chunk, 16000), dtype=torch.float32, device=device) for _ in range(2)]
+    dtype = torch.int16 if pcm16 else torch.float32
+    host = torch.empty((nclips, 16000), dtype=dtype).pin_memory()
+    if pcm16:
+        host.random_(-3277, 3277)
+    else:
+        host.normal_(0.0, 0.1)
+    bufs = [torch.empty((chunk, 16000), dtype=dtype, device=device) for _ in range(2)]
     out = torch.empty((nclips, RES8["n_labels"]), dtype=torch.float32, device=device)
     copy_s, comp_s = torch.cuda.Stream(device), torch.cuda.current_stream(device)
     ready = [torch.cuda.Event() for _ in range(2)]
@@ -294,8 +313,10 @@ def h2d_record(torch, model, device, nclips):
     for _ in range(reps):
         one_pass()
     dt = (time.perf_counter() - t0) / reps
+    host_bytes = host.element_size()
     del host, bufs
-    return {"clips": nclips, "ms_per_pass": 1e3 * dt, "clips_per_s": nclips / dt, "h2d_GBps": nclips * 64000 / dt / 1e9,
+    return {"clips": nclips, "ms_per_pass": 1e3 * dt, "clips_per_s": nclips / dt,
+            "h2d_GBps": nclips * 16000 * host_bytes / dt / 1e9, "input": "int16 PCM" if pcm16 else "float32",
             "what": "wav in pinned host memory -> logits on the device, copies of 8 192-clip chunks overlapped with compute (two streams); PCIe-bound, reported beside `value`, never as it"}
 
 
@@ -470,6 +491,9 @@ def main():
                     ent = next(v for k, v in summ.items() if "res8h_kernel" in k)
                     roofline["traffic"] = (2.0 * ent["FETCH_SIZE"] + ent["WRITE_SIZE"]) * 1024.0
                     roofline["traffic_source"] = f"static: {rel} (rocprofv3 --pmc of this command, committed; not measured in this run)"
+                    # the summary names the kernel source it profiled: a kernel edited since then is flagged, not quoted silently
+                    profiled = summ.get("_sources", {}).get(KERNEL_SOURCE)
+                    roofline["traffic_profile_matches_kernel_source"] = (profiled == source_digest(KERNEL_SOURCE)) if profiled else None
                     break
                 except Exception:
                     continue
@@ -506,6 +530,7 @@ def main():
         if world == 1 and not args.no_h2d:
             try:
                 out["h2d_inclusive"] = h2d_record(torch, model, device, min(args.batch, 32768))
+                out["h2d_inclusive_pcm16"] = h2d_record(torch, model, device, min(args.batch, 32768), pcm16=True)
             except Exception as exc:
                 out["h2d_inclusive"] = {"error": repr(exc)}
         if world == 1 and not args.no_secondary:

@@ -4,6 +4,7 @@ compact per-kernel summary.  Usage: tools/summarize_prof.py <gpurun_out dir> <ta
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -37,6 +38,13 @@ def main(src, tag, dst="profiles/r03"):
             s.update(meta[k])
             for c, v in d.items():
                 s[c] = sum(v) / len(v)
+    # digests of the kernel sources as profiled (run this right after the profile, before editing them): bench.py compares
+    # the digest with the tree's before it quotes the counters of this summary
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    summary["_sources"] = {}
+    for path in sorted(glob.glob(os.path.join(root, "honk2_amd", "csrc", "*.hip"))):
+        with open(path, "rb") as f:
+            summary["_sources"][os.path.relpath(path, root)] = hashlib.sha256(f.read()).hexdigest()
     with open(os.path.join(dst, f"{tag}_summary.json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
     print(json.dumps(summary, indent=1, sort_keys=True))
