@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
             u32x4 (&nxt_)[NP] = (j & 1) ? BX : BY;                                                    \
             TLOADB(nxt_, j + 1 < JT ? b_addr(j + 1, e_c) : b_addr(0, TAPN))                           \
             __builtin_amdgcn_sched_barrier(0);                                                        \
-            _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], cur_, acc[j][m]) }           \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) { TMF6(AR[m], cur_, acc[j][m]) if (TERMS >= 3) __builtin_amdgcn_sched_barrier(0); } \
             __builtin_amdgcn_sched_barrier(0);                                                        \
         }                                                                                             \
     }

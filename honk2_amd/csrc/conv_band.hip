@@ -51,6 +51,10 @@ __device__ __forceinline__ void band_split4(f32x4 x, u32x2 (&out)[2]) {
 }  // namespace
 
 constexpr int BAND_NT = 4;   // position tiles per wave (half a band)
+#ifndef BAND_ORDER
+#define BAND_ORDER 1      // 1: chain-major MFMA order for three-term products (this file is compiled without hipcc's post-RA scheduler, which would
+                          // deal the chains out again: cnn-trad-pool2 f32 5.42 -> 5.10 ms, cnn-trad-fpool3 6.59 -> 6.41; fences per chain instead: 7.04); 0: term-major
+#endif
 #ifndef BAND_APF
 #define BAND_APF 3            // k-steps of weight-fragment look-ahead (A/B knob)
 #endif
@@ -186,6 +190,15 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
     {                                                                                                      \
         _Pragma("unroll") for (int m = 0; m < MH; ++m) BMF(AR[m][PA], B0[PB], acc[m][J]);                  \
     }
+    // chain-major form (BAND_ORDER 1): the three terms of an accumulator back to back (the dependent MFMA takes its C from the one before it)
+#define BCHAIN(AR, B0, J)                                                                                  \
+    {                                                                                                      \
+        _Pragma("unroll") for (int m = 0; m < MH; ++m) {                                                   \
+            BMF(AR[m][NP - 1], B0[0], acc[m][J]);                                                          \
+            BMF(AR[m][0], B0[NP - 1], acc[m][J]);                                                          \
+            BMF(AR[m][0], B0[0], acc[m][J]);                                                               \
+        }                                                                                                  \
+    }
     // one k-step: B fragments one tile PAIR ahead; (bq0, bq1) hold tiles 0, 1 on entry and tiles 0, 1 of the next step (offset KNEXT)
     // on exit (BAND_NT / 2 pairs per step is even: the buffers keep their roles from step to step)
 #define BSTEP(AR, KCUR, KNEXT)                                                                             \
@@ -203,7 +216,10 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
                 if (1 < ntile) BLOADB(n1_, 1, KNEXT)                                                       \
             }                                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                             \
-            if (jp + 1 < ntile) {                                                                          \
+            if (BAND_ORDER == 1 && TERMS >= 3) {                                                           \
+                if (jp < ntile) BCHAIN(AR, c0_, jp)                                                        \
+                if (jp + 1 < ntile) BCHAIN(AR, c1_, jp + 1)                                                \
+            } else if (jp + 1 < ntile) {                                                                   \
                 if (TERMS >= 3) { BTERM2(1, 0, AR, c0_, c1_, jp) BTERM2(0, 1, AR, c0_, c1_, jp) }          \
                 BTERM2(0, 0, AR, c0_, c1_, jp)                                                             \
             } else if (jp < ntile) {                                                                       \
@@ -239,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
 #undef BLOADB
 #undef BTERM2
 #undef BTERM1
+#undef BCHAIN
 #undef BSTEP
 
     BAND_TS(3)

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
                             IMF(a[s][m][0], bf[1], acc[m]);
                         }
                         IMF(a[s][m][0], bf[0], acc[m]);
+                        if (TERMS >= 3) __builtin_amdgcn_sched_barrier(0);   // the chain stays whole (res8_f16x3.hip, R8H_FENCE)
                     }
                 }
 #pragma unroll

@@ -41,6 +41,9 @@ constexpr int XS = 164;                                        // LDS words per 
 #ifndef FE16_NT
 #define FE16_NT 7
 #endif
+#ifndef FE16_ORDER
+#define FE16_ORDER 0
+#endif
 constexpr int NTT = FE16_NT;                                   // 16-frame tiles per unit
 constexpr int FRM = 16 * NTT;                                  // frames per unit
 constexpr int WG_PER_CU = NTT <= 4 ? 3 : 2;
@@ -370,12 +373,21 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
                 build(ks, j1, bh_n, bl_n);
             }
 #define FMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
+#if FE16_ORDER == 1     // chain-major: the three terms of an accumulator back to back
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                FMF(a[m][1], bh_c, acc[m][j]);
+                FMF(a[m][0], bl_c, acc[m][j]);
+                FMF(a[m][0], bh_c, acc[m][j]);
+            }
+#else
 #pragma unroll
             for (int m = 0; m < 4; ++m) FMF(a[m][1], bh_c, acc[m][j]);
 #pragma unroll
             for (int m = 0; m < 4; ++m) FMF(a[m][0], bl_c, acc[m][j]);
 #pragma unroll
             for (int m = 0; m < 4; ++m) FMF(a[m][0], bh_c, acc[m][j]);
+#endif
 #undef FMF
             bh_c = bh_n;
             bl_c = bl_n;

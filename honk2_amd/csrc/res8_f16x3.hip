@@ -219,14 +219,29 @@ __device__ __forceinline__ void load_a(AFrags& f, __amdgpu_buffer_rsrc_t rs, int
 
 #define MF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
 
+#ifndef R8H_ORDER    // MFMA order inside a (k-step, position tile): 0 chain-major, 1 term-major
+#define R8H_ORDER 0
+#endif
 // the MFMAs of one (k-step, position tile, slot): three-term product, small terms first
 template <int TERMS>
-__device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag& b, f32x4& acc) {
+__device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag& b, f32x4& acc, bool zig = false) {
     if (step_kind(s) == 3) {
         if (TERMS >= 3) MF(a[1], b.p[1], acc);   // a2 b1
         MF(a[0], b.p[0], acc);                   // a1 b1 + a1 b2
     } else {
         if (TERMS >= 3) {
+#if R8H_ORDER == 2      // consecutive MFMAs share an operand: (a2 b1) (a1 b1) (a1 b2), and back again for the next slot
+            if (zig) {
+                MF(a[0], b.p[1], acc);
+                MF(a[0], b.p[0], acc);
+                MF(a[1], b.p[0], acc);
+            } else {
+                MF(a[1], b.p[0], acc);
+                MF(a[0], b.p[0], acc);
+                MF(a[0], b.p[1], acc);
+            }
+            return;
+#endif
             MF(a[1], b.p[0], acc);
             MF(a[0], b.p[1], acc);
         }
@@ -242,8 +257,10 @@ __device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag&
 #ifndef R8H_EPRIO   // wave priority OUTSIDE the k-loops (epilogues, conv_0, staging, tail)
 #define R8H_EPRIO 0
 #endif
-#ifndef R8H_ORDER    // MFMA order inside a (k-step, position tile): 0 chain-major, 1 term-major
-#define R8H_ORDER 0
+#ifndef R8H_FENCE    // 1: a scheduling fence after every accumulator's chain of MFMAs -- hipcc's post-RA scheduler otherwise deals the nine MFMAs of a
+                     // tile out term by term; a dependent MFMA issued right behind its predecessor takes C from the pipe, not from the register
+                     // file, and the kernel runs at its power cap: 11.10 -> 10.73 ms (r3; term-major ON PURPOSE: 11.27)
+#define R8H_FENCE 1
 #endif
 #ifndef R8H_BDEPTH   // position tiles of look-ahead of the k-loop's LDS reads
 #define R8H_BDEPTH 1
@@ -315,9 +332,12 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 5) {
                     if (s == 0) acc[j][0] = acc[j][1] = acc[j][2] = zero;
-                    if (R8H_ORDER == 0 || TERMS < 3) {   // chain-major: the three terms of an accumulator back to back
+                    if (R8H_ORDER != 1 || TERMS < 3) {   // chain-major: the three terms of an accumulator back to back
 #pragma unroll
-                        for (int m = 0; m < 3; ++m) mf_tile<TERMS>(s, fc.a[m], bcur, acc[j][m]);
+                        for (int m = 0; m < 3; ++m) {
+                            mf_tile<TERMS>(s, fc.a[m], bcur, acc[j][m], m & 1);
+                            if (R8H_FENCE && m < 2) __builtin_amdgcn_sched_barrier(0);
+                        }
                     } else {                             // term-major: one B fragment meets the three slots' A fragments in turn
                         const bool kd = step_kind(s) == 3;
 #pragma unroll
