@@ -41,6 +41,9 @@ constexpr int XS = 164;                                        // LDS words per 
 #ifndef FE16_NT
 #define FE16_NT 7
 #endif
+#ifndef FE16_ABLATE   // timing experiments: 1 no power tile, 2 one k-step group per band tile in the mel stage (results wrong)
+#define FE16_ABLATE 0
+#endif
 #ifndef FE16_ORDER
 #define FE16_ORDER 0
 #endif
@@ -425,9 +428,21 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
         const float v = sq[(M0) + mm][j][r >> 1][r & 1];                                       \
         OP;                                                                                    \
     }
+#if FE16_ABLATE & 1   // timing experiment: no power tile (results wrong)
+    {
+        float keep = 0.f;     // (every square stays live: one add per value instead of the LDS traffic)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int j = 0; j < NTT; ++j) keep += (sq[m][j][0][0] + sq[m][j][0][1]) + (sq[m][j][1][0] + sq[m][j][1][1]);
+        if (keep == 12345.f) *pt = keep;
+    }
+    __syncthreads();
+#else
     if (w < 2) { P_PHASE(0, *cell = v) } else { P_PHASE(2, *cell = v) }
     __syncthreads();
     if (w < 2) { P_PHASE(2, *cell += v) } else { P_PHASE(0, *cell += v) }
+#endif
 #undef P_PHASE
     __syncthreads();
     const int nxt = *next_unit;
@@ -456,7 +471,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
         for (int m = 0; m < 3; ++m) {
             const int ns = p.mel_ns[m];
             const float* prow = lds + (4 * p.mel_fb[m] + g) * PS;
-            for (int s0 = 0; s0 < ns; s0 += 4, step += 4) {   // the host pads every tile to a multiple of four steps
+            for (int s0 = 0; s0 < ((FE16_ABLATE & 2) ? 4 : ns); s0 += 4, step += 4) {   // the host pads every tile to a multiple of four steps
                 float a[4], x[4][MEL_SLOTS];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

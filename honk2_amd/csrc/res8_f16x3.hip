@@ -208,13 +208,24 @@ __device__ __forceinline__ void load_b(BFrag& b, const int (&qa)[6], int dB, int
         b.p[1] = lds_read16(base + imm + PART_B);
     }
 }
+#ifndef R8H_WAITS
+#define R8H_WAITS 0
+#endif
 // the six fragments of k-step `sidx` (0 .. 6 * 14 - 1 over the layers): scalar base + per-slot scalar offset + lane offset
 __device__ __forceinline__ void load_a(AFrags& f, __amdgpu_buffer_rsrc_t rs, int voff, int sbase, const int (&om)[3]) {
+#if R8H_WAITS   // requested so that the FIRST fragment a k-step uses (slot 0, part 1: see mf_tile) is the LAST to arrive: one vmcnt wait per k-step, not three
+#pragma unroll
+    for (int m = 2; m >= 0; --m)
+#pragma unroll
+        for (int pt = 1; pt >= 0; --pt)
+            f.a[m][pt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + pt * A_FRAG_B, sbase + om[m], 0));
+#else
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt)
             f.a[m][pt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + pt * A_FRAG_B, sbase + om[m], 0));
+#endif
 }
 
 #define MF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
@@ -242,8 +253,13 @@ __device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag&
             }
             return;
 #endif
+#if R8H_WAITS          // the chain starts on the fragment parts that arrive last (a part 1, b part 2): one LDS wait per tile, not two
+            MF(a[0], b.p[1], acc);
+            MF(a[1], b.p[0], acc);
+#else
             MF(a[1], b.p[0], acc);
             MF(a[0], b.p[1], acc);
+#endif
         }
         MF(a[0], b.p[0], acc);
     }
