@@ -20,6 +20,7 @@ implementations -- the reference's included -- agree); the `data` field says so.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -35,6 +36,7 @@ B_BUILT = 96368                # what kws_forward_wav's two kernels move: + the 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32-input matrix (= fp32 vector) peak
 PEAK_BF16_MFMA_TFLOPS = 2516.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (spec); 2.0 PF sustained on this box (tools/coexec_probe_bf16)
 PEAK_HBM_GBS = 8000.0
+EST_MS_PER_CLIP = 2.1e-4     # wav -> logits, for sizing the pre-warm only
 KERNEL_SOURCE = "honk2_amd/csrc/res8_f16x3.hip"
 
 
@@ -244,17 +246,17 @@ def secondary_configs(torch, device):
 
 def shard_record(torch, model, device, full_rate, full_k_ms, full_f_ms, full_clips):
     """The per-GPU workload of BASELINE configs[3] at 8 GPUs (65 536 / 8 = 8 192 clips) measured on this one GPU: wav -> logits,
-    20 steps; efficiency = its clip rate over the full batch's (1.0 = an 8-GPU run would hold the 1-GPU per-clip cost)."""
+    100 steps after ~300 ms of load; efficiency = its clip rate over the full batch's (1.0 = an 8-GPU run would hold the 1-GPU per-clip cost)."""
     n = 8192
     wav = synth_wav(torch, 0, n, 1234, device)
     out = torch.empty((n, RES8["n_labels"]), dtype=torch.float32, device=device)
     engine = model.engine()
-    for _ in range(3):
+    for _ in range(int(math.ceil(300.0 / (n * EST_MS_PER_CLIP)))):     # ~300 ms of load first: see main()
         model.forward_wav(wav, out=out)
     torch.cuda.synchronize()
     engine.profile_enable(True)
     engine.profile_read()
-    steps = 20
+    steps = 100
     t0 = time.perf_counter()
     for _ in range(steps):
         model.forward_wav(wav, out=out)
@@ -344,6 +346,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed load before the W warm-up steps (clock governor); 0 = none")
     ap.add_argument("--batch", type=int, default=65536, help="GLOBAL batch (clips per step over all GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] records (N = 1 only)")
@@ -427,6 +430,12 @@ def main():
             else:
                 gbufs[0].copy_(dist_utils.all_gather_rows(lbufs[0], counts))
 
+    # The clock governor needs ~100 ms of load to settle: the same 8 192-clip launches average 0.44 ms each over 10 repetitions from idle
+    # and 0.35 ms over 1 000 (tools/ramp_probe.sh).  A step of the N = 8 run is 1.8 ms, so W = 5 warm-up steps would leave the K timed ones on
+    # the ramp; an untimed pre-warm of ~args.prewarm_ms (a step count fixed by the shard size, the same on every rank) comes first.
+    prewarm_steps = min(400, int(math.ceil(args.prewarm_ms / max(nloc * EST_MS_PER_CLIP, 1e-3)))) if args.prewarm_ms > 0 else 0
+    for _ in range(prewarm_steps):
+        step()
     for _ in range(args.warmup):
         step()
     engine = model.engine()
@@ -499,7 +508,8 @@ def main():
                     continue
         out = {
             "metric": "1s-clips/sec end-to-end (wav->logits), res8 GSCv2", "value": clips_per_s, "unit": "clips/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm": {"steps": prewarm_steps, "target_ms": args.prewarm_ms, "what": "untimed steps before the W warm-up steps: the clock governor settles over ~100 ms of load"},
+            "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": ("f32 (f16x3: fp32-accurate 3-term fp16 products, fp32 accumulate, in the conv stack and in the front end's DFT)" if plan == "res8_fused" else "f32 (bf16x6: fp32-accurate 6-term bf16 products, fp32 accumulate; fp32 front end)" if plan == "res8_fused_bf16x6" else "f32"), "data": "synthetic (SURVEY.md 8d inputs; deviation: the 1 kHz tone clips carry their clip's noise at -37 dB as dither)",
             "config": {"workload": f"res8 fp32 wav->logits, global batch {args.batch} one-second 16 kHz clips "
                                    f"(BASELINE configs[3]), {nloc} clips/GPU, random-init weights",

@@ -488,6 +488,35 @@ def test_layer_pairs_in_one_kernel_are_bit_identical(torch_cuda, dtype, case, mo
     assert torch.isfinite(got).all() and torch.equal(got, want), float((got - want).abs().max())
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_layer_pairs_on_odd_shapes(torch_cuda, dtype, monkeypatch):
+    """The pair kernel where no shipped config puts it: maps smaller than one workgroup tile (a batch of one 23-frame clip), a map whose
+    flattened positions end inside a tile, a pooled map, dilations that reach past the map, 19 and 45 channels.  Bit-identical to the
+    one-kernel-per-layer form, and within the 16-bit tolerance of the fp32 oracle (reference model/resnet.py:38-60)."""
+    torch = torch_cuda
+    from oracle import models, weights
+    rng = np.random.default_rng(31)
+    for cfg, T, B in [
+        ({"n_feature_maps": 45, "n_layers": 6, "use_dilation": True, "n_labels": 12}, 23, 1),
+        ({"n_feature_maps": 45, "n_layers": 13, "use_dilation": True, "n_labels": 12}, 37, 3),
+        ({"n_feature_maps": 19, "n_layers": 8, "use_dilation": False, "n_labels": 5}, 61, 5),
+        ({"n_feature_maps": 45, "n_layers": 8, "use_dilation": False, "pool": [3, 2], "n_labels": 12}, 64, 2),
+    ]:
+        sd = weights.make_state_dict("ResNet", cfg, seed=23)
+        feats = (rng.standard_normal((B, T, 40)) * 2.5 + 0.65).astype(np.float32)
+        x = torch.from_numpy(feats).cuda()
+        monkeypatch.setenv("KWS_T3_PAIR", "1")
+        fused = _build(torch, "ResNet", dict(cfg, dtype=dtype), sd)
+        got = fused(x)
+        assert fused.plan_name() == "resnet_tiled", (cfg, fused.plan_name())
+        monkeypatch.setenv("KWS_T3_PAIR", "0")
+        want = _build(torch, "ResNet", dict(cfg, dtype=dtype), sd)(x)
+        assert torch.isfinite(got).all() and torch.equal(got, want), (cfg, float((got - want).abs().max()))
+        ref = models.forward_torch("ResNet", cfg, sd, feats).numpy()
+        err = np.abs(got.cpu().numpy() - ref).max()
+        assert err < (2e-2 if dtype == "bf16" else 5e-3) * max(1.0, np.abs(ref).max()), (cfg, dtype, err)   # SURVEY.md Appendix C
+
+
 def test_fused_res8_takes_any_fp32_feature_range(torch_cuda):
     """The reference's ResNet.forward takes any finite fp32 feature (model/resnet.py:39-41); the fused res8 kernel stages features
     as fp16 pairs.  kws_forward therefore measures every clip's feature range on the device and the kernel stages out-of-range
@@ -861,19 +890,20 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(torch_cuda, tmp_path):
     env = dict(os.environ, KWS_BENCH_BACKEND="gloo", KWS_BENCH_ONE_DEVICE="1", KWS_BENCH_DUMP=str(tmp_path / "n2.npy"))
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2048"],
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2048", "--prewarm-ms", "0"],
                          env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert two.returncode == 0, two.stderr[-2000:]
     line2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
     assert line2["n_gpus"] == 2 and line2["config"]["clips_per_gpu"] == 1024 and line2["config"]["global_batch"] == 2048
     assert line2["steps"] == 2 and line2["warmup"] == 1 and line2["value"] > 0 and line2["scaling"] == "strong"
-    assert "cpu_baseline" not in line2 and line2["roofline"]["launches"] == 2
+    assert "cpu_baseline" not in line2 and line2["roofline"]["launches"] == 2 and line2["prewarm"]["steps"] == 0
     env1 = dict(os.environ, KWS_BENCH_DUMP=str(tmp_path / "n1.npy"))
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                           "--batch", "2048", "--no-cpu-baseline", "--no-secondary"], env=env1, capture_output=True, text=True, timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
     line1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert line1["n_gpus"] == 1 and line1["config"]["clips_per_gpu"] == 2048
+    assert 0 < line1["prewarm"]["steps"] <= 400 and line1["roofline"]["launches"] == 2     # the untimed clock-governor pre-warm is not in the timed region
     a, b = np.load(tmp_path / "n1.npy"), np.load(tmp_path / "n2.npy")
     assert a.shape == b.shape == (2048, 12) and np.array_equal(a, b)
     # the RCCL leg gathers on a side stream while the next step computes (two buffers in rotation): the same stream / event logic

@@ -12,7 +12,7 @@ ap.compute_mfccs_batch(wav[:1024])
 for _ in range(2): f = ap.compute_mfccs_batch(wav)
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-reps = 10
+reps = int(os.environ.get("FE_REPS", "10"))
 ev[0].record()
 for _ in range(reps): f = ap.compute_mfccs_batch(wav)
 ev[1].record(); torch.cuda.synchronize()
