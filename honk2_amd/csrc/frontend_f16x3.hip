@@ -41,7 +41,7 @@ constexpr int XS = 164;                                        // LDS words per 
 #ifndef FE16_NT
 #define FE16_NT 7
 #endif
-#ifndef FE16_ABLATE   // timing experiments: 1 no power tile, 2 one k-step group per band tile in the mel stage (results wrong)
+#ifndef FE16_ABLATE   // timing experiments: 1 no power tile, 2 one k-step group per band tile in the mel stage, 4 no B-fragment builds in the k-loop (results wrong)
 #define FE16_ABLATE 0
 #endif
 #ifndef FE16_ORDER
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
             if (idx + 1 < 4 * NTT) {
                 const int s1 = (idx + 1) / NTT, j1 = (idx + 1) - s1 * NTT;
                 if (j1 == 0) setup(s1, ks);
-                build(ks, j1, bh_n, bl_n);
+                if (!(FE16_ABLATE & 4)) build(ks, j1, bh_n, bl_n);     // (4: one B fragment for the whole k-loop -- no LDS reads, folds or splits)
             }
 #define FMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
 #if FE16_ORDER == 1     // chain-major: the three terms of an accumulator back to back

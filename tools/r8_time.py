@@ -17,8 +17,13 @@ for k, v in sd.items():
 model.load_state_dict(sd)
 model = model.cuda().eval()
 x = torch.randn(B, 101, 40, device="cuda") * 2.5 + 0.65
+import time
 for _ in range(3): y = model(x)
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < float(os.environ.get("R8_SETTLE_S", "0.3")):   # the clock governor settles over ~100 ms of load (tools/ramp_probe.sh)
+    y = model(x)
+    torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 reps = int(os.environ.get("R8_REPS", "10"))
 ev[0].record()
