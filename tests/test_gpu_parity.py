@@ -612,6 +612,83 @@ def test_size_independent_properties_at_full_batch(torch_cuda):
     assert torch.equal(full[0], full[12]) and torch.isfinite(full).all()  # all-zero clips agree
 
 
+@pytest.mark.parametrize("fname", ["model_resnet__res8.npz", "model_resnet__res15.npz", "model_cnn__cnn-trad-pool2.npz"])
+def test_forward_wav_is_graph_capturable_after_one_warm_up_call(torch_cuda, fname):
+    """include/kws.h: a compute call does no host synchronisation and no allocation once the first call per clip length has run, so
+    a call sequence can be captured into a hipGraph.  Capture wav -> logits (front end + model, the counter resets between them)
+    and mfcc alone, replay on new input, compare with the eager calls bit for bit."""
+    torch = torch_cuda
+    from oracle import weights
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    model = _build(torch, name, cfg, sd)
+    wav = torch.from_numpy(weights.make_waveforms(48, seed=5)).cuda()
+    wav2 = torch.from_numpy(weights.make_waveforms(48, seed=6)).cuda()
+    static_in = wav.clone()
+    out = torch.empty((48, cfg["n_labels"]), dtype=torch.float32, device="cuda")
+    want1 = model.forward_wav(wav).clone()            # the warm-up call: parameters finalised, tables of this clip length built
+    want2 = model.forward_wav(wav2).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        model.forward_wav(static_in, out=out)          # (on the capture stream once, un-captured)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            model.forward_wav(static_in, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    for src, want in ((wav2, want2), (wav, want1), (wav2, want2)):
+        static_in.copy_(src)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), float((out - want).abs().max())
+
+
+@pytest.mark.parametrize("fname", ["model_resnet__res8.npz", "model_cnn__cnn-tpool2.npz"])
+def test_plain_c_client_of_the_abi(torch_cuda, fname, tmp_path):
+    """The drop-in boundary is a C ABI: tests/c_abi/kws_c_client.c (gcc, libkws_hip.so + the HIP runtime, no Python, no PyTorch; device
+    memory and a stream of its own) loads the same state dict through kws_load_weights and runs kws_forward_wav / kws_forward_pcm16.
+    Its logits must equal the Python host's bit for bit (the host is plumbing, not arithmetic)."""
+    import ctypes
+    import shutil
+    import struct
+    import subprocess
+    torch = torch_cuda
+    from oracle import weights
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no gcc / HIP headers on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "kws_c_client")
+    libdir = os.path.join(root, "honk2_amd")
+    build = subprocess.run(["gcc", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                            os.path.join(root, "tests", "c_abi", "kws_c_client.c"), "-o", exe, "-L" + libdir, "-lkws_hip", "-L/opt/rocm/lib",
+                            "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    model = _build(torch, name, cfg, sd)
+    wav = weights.make_waveforms(40, seed=9)
+    bundle = tmp_path / "bundle.bin"
+    with open(bundle, "wb") as f:
+        f.write(bytes(model._make_desc()))
+        f.write(struct.pack("<i", len(sd)))
+        for key, val in sd.items():
+            if key.endswith("num_batches_tracked"):
+                val = np.zeros(1, np.float32)            # (accepted and ignored by kws_load_weights)
+            data = np.ascontiguousarray(val, dtype=np.float32).tobytes()
+            f.write(struct.pack("<i", len(key)) + key.encode() + struct.pack("<q", len(data)) + data)
+        f.write(struct.pack("<ii", wav.shape[0], wav.shape[1]) + np.ascontiguousarray(wav, dtype=np.float32).tobytes())
+    want = model.forward_wav(torch.from_numpy(wav).cuda()).cpu().numpy()
+    pcm = np.clip(np.where(wav < 0, wav * 32768.0 - 0.5, wav * 32768.0 + 0.5), -32768, 32767).astype(np.int16)   # the client's rounding
+    want_pcm = model.forward_wav(torch.from_numpy(pcm).cuda()).cpu().numpy()
+    for extra, ref in (([], want), (["pcm"], want_pcm)):
+        out = tmp_path / ("logits_pcm.bin" if extra else "logits.bin")
+        run = subprocess.run([exe, str(bundle), str(out)] + extra, capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, (run.stdout, run.stderr[-2000:])
+        assert model.plan_name() in run.stdout
+        got = np.fromfile(out, dtype=np.float32).reshape(ref.shape)
+        assert np.array_equal(got, ref), np.abs(got - ref).max()
+
+
 def test_empty_batch_and_errors(torch_cuda):
     torch = torch_cuda
     from oracle import weights
