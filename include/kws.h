@@ -22,7 +22,7 @@
  *     library BORROWS them for the duration of the call and never frees them).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every compute call is
  *     asynchronous on that stream and performs no host synchronisation and no allocation, so a call
- *     sequence can be captured into a hipGraph -- with two one-time exceptions, both on the FIRST compute
+ *     sequence can be captured into a hipGraph (launches of one handle must still not overlap: INTEGRATION.md section 2) -- with two one-time exceptions, both on the FIRST compute
  *     call that needs them (so: run one un-captured warm-up call per clip length first): the re-packed
  *     parameters are uploaded when the first call after kws_load_weights finalises them, and the tiled
  *     ResNet plan (res15 / res26 / narrow models, res8 on clips that are not one second long) builds and
