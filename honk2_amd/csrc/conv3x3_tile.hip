@@ -397,9 +397,10 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = relu1(fmaf(acc[j][m][r], p.inv_scale, bb[r]));   // inv_scale = 2^-S of the fp16 weights (1 for bf16)
-                if (resp) x += rv[r];
-                v[r] = co0 + r < p.Cout ? x : 0.f;   // padded channels hold exact zeros
+                // inv_scale = 2^-S of the fp16 weights (1 for bf16).  No test on the channel index: the padded output channels meet zero weight
+                // rows, a zero border bias and the zero padded channels of the residual, so they come out as the exact zeros the next layer's
+                // K padding needs (r3: three VALU per value less); rv is 0 without a residual (x + 0 = x exactly, x >= +0)
+                v[r] = relu1(fmaf(acc[j][m][r], p.inv_scale, bb[r])) + rv[r];
                 amax = fmaxf(amax, fabsf(v[r]));
             }
             if (p.debug & 4) continue;
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float x = relu1(fmaf(acc[j][m][r], p.inv_scale_a, bb[r]));
-                    v[r] = (co0 + r < p.Cout && ((tmask[j] >> 13) & 1)) ? x : 0.f;
+                    v[r] = ((tmask[j] >> 13) & 1) ? x : 0.f;     // (padded channels are exact zeros by construction: see conv3x3_tile_kernel)
                     amax = fmaxf(amax, fabsf(v[r]));
                 }
                 *reinterpret_cast<u32x2*>(lds + mid_off + lm * CELL + co0 * 2) = cl_pack4<F16>(v);
@@ -764,8 +765,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float x = relu1(fmaf(acc[j][m][r], p.inv_scale_b, bb[r])) + rv[r];
-                    v[r] = co0 + r < p.Cout ? x : 0.f;
+                    v[r] = relu1(fmaf(acc[j][m][r], p.inv_scale_b, bb[r])) + rv[r];
                     amax = fmaxf(amax, fabsf(v[r]));
                 }
                 if (!(p.debug & 4)) *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
