@@ -703,7 +703,9 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
 #pragma unroll
         for (int j = 0; j < JTA; ++j) {
             const int lm = (w * JTA + j) * 16 + pcol;
-            if (lm >= n_mid) continue;
+            // cells outside the tensor and the padding positions of partial sub-maps are skipped (lane mask, no per-value select): every tap of
+            // conv_{i+1} that would land on one is dead in the consumer's own mask and reads the zero cell instead
+            if (lm >= n_mid || !((tmask[j] >> 13) & 1)) continue;
             const int bmask = (tmask[j] >> 9) & 15;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -713,8 +715,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float x = relu1(fmaf(acc[j][m][r], p.inv_scale_a, bb[r]));
-                    v[r] = ((tmask[j] >> 13) & 1) ? x : 0.f;     // (padded channels are exact zeros by construction: see conv3x3_tile_kernel)
+                    v[r] = relu1(fmaf(acc[j][m][r], p.inv_scale_a, bb[r]));     // (padded channels are exact zeros by construction: see conv3x3_tile_kernel)
                     amax = fmaxf(amax, fabsf(v[r]));
                 }
                 *reinterpret_cast<u32x2*>(lds + mid_off + lm * CELL + co0 * 2) = cl_pack4<F16>(v);
