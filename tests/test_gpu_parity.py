@@ -689,6 +689,31 @@ def test_plain_c_client_of_the_abi(torch_cuda, fname, tmp_path):
         assert np.array_equal(got, ref), np.abs(got - ref).max()
 
 
+def test_two_handles_on_two_streams_are_independent(torch_cuda):
+    """include/kws.h: distinct handles are independent.  Two models (a fused res8 and a tiled res15, each with its own work-queue words,
+    workspace and range-guard state) run wav -> logits concurrently on two streams; every result must equal the one computed alone."""
+    torch = torch_cuda
+    from oracle import weights
+    _, name8, cfg8, sd8, _, _ = load_golden_model("model_resnet__res8.npz")
+    _, name15, cfg15, sd15, _, _ = load_golden_model("model_resnet__res15.npz")
+    m8, m15 = _build(torch, name8, cfg8, sd8), _build(torch, name15, cfg15, sd15)
+    wav8 = torch.from_numpy(weights.make_waveforms(3000, seed=41)).cuda()
+    wav15 = torch.from_numpy(weights.make_waveforms(300, seed=42)).cuda()
+    want8, want15 = m8.forward_wav(wav8).clone(), m15.forward_wav(wav15).clone()
+    s8, s15 = torch.cuda.Stream(), torch.cuda.Stream()
+    out8 = [torch.empty_like(want8) for _ in range(4)]
+    out15 = [torch.empty_like(want15) for _ in range(4)]
+    torch.cuda.synchronize()
+    for i in range(4):
+        with torch.cuda.stream(s8):
+            m8.forward_wav(wav8, out=out8[i])
+        with torch.cuda.stream(s15):
+            m15.forward_wav(wav15, out=out15[i])
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert torch.equal(out8[i], want8) and torch.equal(out15[i], want15), i
+
+
 def test_empty_batch_and_errors(torch_cuda):
     torch = torch_cuda
     from oracle import weights
