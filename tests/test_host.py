@@ -273,3 +273,25 @@ def test_models_deepcopy_and_pickle_without_their_engines():
         assert all(torch.equal(a, b) for a, b in zip(clone.state_dict().values(), model.state_dict().values()))
         assert not clone.training
     assert model._engines[0][0] == "sentinel"
+
+
+def test_header_is_plain_c_and_the_c_client_links(tmp_path):
+    """include/kws.h must compile as C99 with nothing but <stddef.h> / <stdint.h>, and tests/c_abi/kws_c_client.c must link against
+    libkws_hip.so + the HIP runtime alone (the -m gpu suite runs it)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "kws.h"\nint main(void) { kws_model_desc d; d.struct_size = (int32_t)sizeof d; return d.struct_size == 0 || KWS_ABI_VERSION == 0 || KWS_OK != 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(probe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lib = os.path.join(ROOT, "honk2_amd", "libkws_hip.so")
+    if not (os.path.exists(lib) and os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h")):
+        pytest.skip("library not built or no HIP headers")
+    r = subprocess.run(["gcc", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c_abi", "kws_c_client.c"), "-o", str(tmp_path / "kws_c_client"),
+                        "-L" + os.path.join(ROOT, "honk2_amd"), "-lkws_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                        "-Wl,-rpath," + os.path.join(ROOT, "honk2_amd"), "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
