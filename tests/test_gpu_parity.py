@@ -714,6 +714,23 @@ def test_two_handles_on_two_streams_are_independent(torch_cuda):
         assert torch.equal(out8[i], want8) and torch.equal(out15[i], want15), i
 
 
+@pytest.mark.parametrize("fname,dtype", [("model_resnet__res15.npz", "f32"), ("model_resnet__res15.npz", "bf16"), ("model_resnet__res26.npz", "fp16"),
+                                         ("model_cnn__cnn-trad-pool2.npz", "f32"), ("model_cnn__cnn-one-fstride4.npz", "fp16")])
+def test_a_clips_logits_do_not_depend_on_its_neighbours(torch_cuda, fname, dtype):
+    """Clips are independent units (BatchNorm in eval mode, reference run/test.py:21): on every plan -- the tiled kernels run over the
+    flattened batch, workgroup tiles straddle clips -- a clip's logits are the same bits whatever batch it sits in, and wherever."""
+    torch = torch_cuda
+    from oracle import weights
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    model = _build(torch, name, dict(cfg, dtype=dtype), sd)
+    x = torch.from_numpy(weights.make_features(53, seed=77)).cuda()
+    full = model(x)
+    perm = torch.randperm(53, generator=torch.Generator().manual_seed(5)).cuda()
+    assert torch.equal(model(x[perm].contiguous()), full[perm])
+    assert torch.equal(model(x[:7].contiguous()), full[:7])
+    assert torch.equal(model(x[20:21].contiguous()), full[20:21])
+
+
 def test_empty_batch_and_errors(torch_cuda):
     torch = torch_cuda
     from oracle import weights
