@@ -994,6 +994,90 @@ __global__ __launch_bounds__(256) void conv0_cl_kernel(const float* __restrict__
     range_note(rg, amax);
 }
 
+// (r3) The pooled form for the shipped pooling windows (PKH x PKW = 2 x 2: res26; 4 x 3: the res8 family on the tiled plan): one thread = one pooled
+// position x one 16-byte chunk of channels; the (PKH + 2) x (PKW + 2) window of the feature map is loaded once (16 / 30 words instead of 36 / 108
+// bounds-checked loads -- the generic loop spends three times as many vector instructions on indices and bounds as on FMAs).  Same FMA, ReLU-sum and
+// division order as conv0_cl_kernel: bit-identical.
+template <int CLT, int PKH, int PKW>
+__global__ __launch_bounds__(256) void conv0_cl_pool_kernel(const float* __restrict__ feat, const float* __restrict__ w9 /*[9][cp]*/, void* __restrict__ out,
+                                                            long long total /* threads */, int T, int F, int Hp, int Wp, int cp, RangeGate rg) {
+    if (range_gate_closed(rg)) return;
+    constexpr int EPT = CLT == CL_F32 ? 4 : 8;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int nq = cp / EPT;
+    const int q = (int)(i % nq);
+    const long long pos = i / nq;
+    float w[9][EPT];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < EPT; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(w9 + k * cp + EPT * q + e);
+            w[k][e] = t[0]; w[k][e + 1] = t[1]; w[k][e + 2] = t[2]; w[k][e + 3] = t[3];
+        }
+    const int ox = (int)(pos % Wp);
+    const long long t = pos / Wp;
+    const int oy = (int)(t % Hp);
+    const long long b = t / Hp;
+    const float* src = feat + b * (long long)T * F;
+    const int y0 = oy * PKH - 1, x0 = ox * PKW - 1;       // window origin; rows y0+1 .. y0+PKH and columns x0+1 .. x0+PKW are always inside the map
+    float win[PKH + 2][PKW + 2];
+#pragma unroll
+    for (int r = 0; r < PKH + 2; ++r) {
+        const int yy = y0 + r;
+        const bool rok = (r >= 1 && r <= PKH) || (yy >= 0 && yy < T);
+        const float* row = src + (long long)min(max(yy, 0), T - 1) * F;
+#pragma unroll
+        for (int c = 0; c < PKW + 2; ++c) {
+            const int xx = x0 + c;
+            const bool ok = rok && ((c >= 1 && c <= PKW) || (xx >= 0 && xx < F));
+            const float v = row[min(max(xx, 0), F - 1)];
+            win[r][c] = ok ? v : 0.f;
+        }
+    }
+    float sum[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) sum[e] = 0.f;
+#pragma unroll
+    for (int my = 0; my < PKH; ++my)
+#pragma unroll
+        for (int mx = 0; mx < PKW; ++mx) {
+            float c[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) c[e] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) c[e] = fmaf(w[3 * ky + kx][e], win[my + ky][mx + kx], c[e]);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) sum[e] += fmaxf(c[e], 0.f);
+        }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) sum[e] = sum[e] / (float)(PKH * PKW);   // a true division, as nn.AvgPool2d's sum / count
+    const long long o = pos * cp + EPT * q;
+    if (CLT == CL_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + o) = (f32x4){sum[0], sum[1], sum[2], sum[3]};
+    else {
+        const u32x2 lo = cl_pack4<CLT == CL_F16>((f32x4){sum[0], sum[1], sum[2], sum[3]});
+        const u32x2 hi = cl_pack4<CLT == CL_F16>((f32x4){sum[EPT - 4], sum[EPT - 3], sum[EPT - 2], sum[EPT - 1]});
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(out) + o) = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) amax = fmaxf(amax, fabsf(sum[e]));
+    range_note(rg, amax);
+}
+
+template <int PKH, int PKW>
+static hipError_t launch_conv0_cl_pool(const float* feat, const float* w9, void* out, int cl_type, long long total, int T, int F, int Hp, int Wp, int cp,
+                                       hipStream_t s, RangeGate rg) {
+    auto k = cl_type == CL_BF16 ? conv0_cl_pool_kernel<CL_BF16, PKH, PKW> : cl_type == CL_F16 ? conv0_cl_pool_kernel<CL_F16, PKH, PKW> : conv0_cl_pool_kernel<CL_F32, PKH, PKW>;
+    hipLaunchKernelGGL(k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, w9, out, total, T, F, Hp, Wp, cp, rg);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv0_cl(const float* feat, const float* w9, void* out, int cl_type, int B, int T, int F, int kh, int kw, int cp,
                            hipStream_t s, RangeGate rg) {
     const int Hp = T / kh, Wp = F / kw;
@@ -1001,6 +1085,8 @@ hipError_t launch_conv0_cl(const float* feat, const float* w9, void* out, int cl
     const int px = kh * kw > 1 ? 1 : 4;
     const long long total = (npos + px - 1) / px * (cp / (cl_type == CL_F32 ? 4 : 8));
     if (total <= 0) return hipSuccess;
+    if (kh == 2 && kw == 2) return launch_conv0_cl_pool<2, 2>(feat, w9, out, cl_type, total, T, F, Hp, Wp, cp, s, rg);
+    if (kh == 4 && kw == 3) return launch_conv0_cl_pool<4, 3>(feat, w9, out, cl_type, total, T, F, Hp, Wp, cp, s, rg);
     auto k = px == 1 ? (cl_type == CL_BF16 ? conv0_cl_kernel<CL_BF16, 1> : cl_type == CL_F16 ? conv0_cl_kernel<CL_F16, 1> : conv0_cl_kernel<CL_F32, 1>)
                      : (cl_type == CL_BF16 ? conv0_cl_kernel<CL_BF16, 4> : cl_type == CL_F16 ? conv0_cl_kernel<CL_F16, 4> : conv0_cl_kernel<CL_F32, 4>);
     // row-aligned fast path: a thread's four positions lie in one row of one clip and its rows are 16-byte aligned
