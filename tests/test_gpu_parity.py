@@ -319,6 +319,92 @@ def test_cnn_geometries_beyond_the_shipped_configs(torch_cuda, case, dtype):
     assert np.abs(got - want).max() < tol, (case, dtype, np.abs(got - want).max())
 
 
+def _random_resnet(rng):
+    cfg = {"n_feature_maps": int(rng.choice([8, 16, 19, 24, 30, 45, 48])), "n_layers": int(rng.integers(2, 10)),
+           "use_dilation": bool(rng.integers(0, 2)), "n_labels": int(rng.integers(2, 13))}
+    if rng.integers(0, 3) == 0:
+        cfg["pool"] = [int(rng.integers(1, 5)), int(rng.integers(1, 4))]
+    return cfg, int(rng.integers(9, 131)), int(rng.integers(1, 10))
+
+
+def _random_cnn(rng):
+    time, freq = int(rng.integers(40, 111)), int(rng.choice([24, 32, 40, 42, 48]))
+    k0 = [int(rng.integers(4, 25)), int(rng.choice([4, 8, 8, 8, 10]))]
+    s0 = [int(rng.integers(1, 3)), int(rng.integers(1, 3))]
+    p0 = [int(rng.integers(1, 4)), int(rng.integers(1, 4))]
+    cfg = {"time": time, "frequency": freq, "dropout_prob": 0.5, "n_labels": int(rng.integers(2, 13)),
+           "conv_0": {"out_channels": int(rng.choice([16, 30, 54, 64, 94])), "kernel_size": k0, "stride": s0}, "pool_0": {"kernel_size": p0}}
+    h = ((time - k0[0]) // s0[0] + 1) // p0[0]
+    w = ((freq - k0[1]) // s0[1] + 1) // p0[1]
+    if h < 1 or w < 1:
+        return None
+    if rng.integers(0, 2) and h >= 6 and w >= 4:
+        k1 = [int(rng.integers(2, min(h, 10) + 1)), int(rng.integers(1, min(w, 5) + 1))]
+        cfg["conv_1"] = {"out_channels": int(rng.choice([24, 40, 64, 78])), "kernel_size": k1, "stride": [int(rng.integers(1, 3)), 1]}
+        cfg["pool_1"] = {"kernel_size": [1, 1] if rng.integers(0, 2) else [int(rng.integers(1, 3)), int(rng.integers(1, 3))]}
+        h1 = ((h - k1[0]) // cfg["conv_1"]["stride"][0] + 1) // cfg["pool_1"]["kernel_size"][0]
+        w1 = ((w - k1[1]) + 1) // cfg["pool_1"]["kernel_size"][1]
+        if h1 < 1 or w1 < 1:
+            return None
+    if rng.integers(0, 2):
+        cfg["lin_0"] = {"out_features": int(rng.choice([16, 32]))}
+        if rng.integers(0, 2):
+            cfg["dnn_0"] = {"out_features": int(rng.choice([32, 128]))}
+    return cfg
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108])
+def test_seeded_random_model_geometries_against_the_oracle(torch_cuda, seed):
+    """A seeded sweep over model configurations the reference's constructors accept (model/resnet.py:11-36, model/cnn.py:12-77) but no
+    shipped config uses: channel counts, depths, dilation, pooling windows, kernel sizes, strides, clip lengths, batch sizes.  Whatever plan
+    the library picks for a configuration (fused, tiled, pair, band, image, generic), the fp32 logits must match the fp32 CPU oracle."""
+    torch = torch_cuda
+    from oracle import models, weights
+    rng = np.random.default_rng(seed)
+    plans = set()
+    for trial in range(8):
+        cfg, T, B = _random_resnet(rng)
+        sd = weights.make_state_dict("ResNet", cfg, seed=seed * 100 + trial)
+        feats = (rng.standard_normal((B, T, 40)) * 2.5 + 0.65).astype(np.float32)
+        model = _build(torch, "ResNet", cfg, sd)
+        got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
+        want = models.forward_torch("ResNet", cfg, sd, feats).numpy()
+        plans.add(model.plan_name())
+        assert np.abs(got - want).max() < LOGIT_TOL * max(1.0, float(np.abs(want).max())), ("ResNet", cfg, T, B, model.plan_name(), np.abs(got - want).max())
+    done = 0
+    while done < 8:
+        cfg = _random_cnn(rng)
+        if cfg is None:
+            continue
+        done += 1
+        sd = weights.make_state_dict("CNN", cfg, seed=seed * 100 + 50 + done)
+        feats = weights.make_features(int(rng.integers(1, 12)), seed=seed + done, time=cfg["time"], freq=cfg["frequency"])
+        model = _build(torch, "CNN", cfg, sd)
+        got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
+        want = models.forward_torch("CNN", cfg, sd, feats).numpy()
+        plans.add(model.plan_name())
+        assert np.abs(got - want).max() < LOGIT_TOL * max(1.0, float(np.abs(want).max())), ("CNN", cfg, model.plan_name(), np.abs(got - want).max())
+    assert len(plans) >= 3, plans
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_seeded_random_resnets_in_the_16_bit_dtypes(torch_cuda, dtype):
+    """The same sweep for the 16-bit tensor forms of the tiled / pair kernels (and whatever falls back to the generic ones), at the
+    SURVEY.md Appendix C tolerances."""
+    torch = torch_cuda
+    from oracle import models, weights
+    rng = np.random.default_rng(211)
+    for trial in range(16):
+        cfg, T, B = _random_resnet(rng)
+        sd = weights.make_state_dict("ResNet", cfg, seed=900 + trial)
+        feats = (rng.standard_normal((B, T, 40)) * 2.5 + 0.65).astype(np.float32)
+        model = _build(torch, "ResNet", dict(cfg, dtype=dtype), sd)
+        got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
+        want = models.forward_torch("ResNet", cfg, sd, feats).numpy()
+        tol = (2e-2 if dtype == "bf16" else 5e-3) * max(1.0, float(np.abs(want).max()))
+        assert np.isfinite(got).all() and np.abs(got - want).max() < tol, (cfg, T, B, dtype, model.plan_name(), np.abs(got - want).max(), np.abs(want).max())
+
+
 @pytest.mark.parametrize("impl", ["nchw", "fp32"])
 @pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_resnet__res26_narrow.npz", "model_cnn__cnn-tpool2.npz"])
 def test_alternative_layerwise_kernels_agree(torch_cuda, monkeypatch, fname, impl):
