@@ -48,6 +48,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef int int2_ __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+// B-fragment reads take 32-bit LDS addresses (res8_f16x3.hip): `lds + offset` costs a vector add of the `lds` symbol per read, a plain LDS
+// integer does not.  The kernels below hold only dynamic LDS, which therefore starts at LDS address 0 (checked once per workgroup).
+typedef const u32x4 __attribute__((address_space(3))) * t3_lds_u32x4_ptr;
+__device__ __forceinline__ u32x4 t3_lds_read16(int addr) { return *reinterpret_cast<t3_lds_u32x4_ptr>((unsigned)addr); }
+__device__ __forceinline__ void t3_require_lds_base_zero(const char* lds) {
+    if ((unsigned)reinterpret_cast<uintptr_t>(lds) != 0u) __builtin_trap();
+}
 
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -163,6 +170,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
     constexpr int UNR = S16 ? (NB == 6 ? (TILE_P <= 192 ? 7 : (TILE_P <= 320 ? 10 : 13)) : 4) : (NB == 6 ? 10 : 5);  // staging passes in flight together
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
+    t3_require_lds_base_zero(lds);
 #ifdef T3_TIMING   // 100 MHz wall-clock stamps of this workgroup's phases (tools/t3_phases.py)
     unsigned long long t3ts[12];
 #define T3_TS(i) t3ts[i] = __builtin_amdgcn_s_memrealtime();
@@ -188,8 +196,10 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
     }
     const int P0 = tile_id * TILE_P;
     const int ncell = TILE_P + 2 * Ws + 2;
-    const int zero_off = ncell * CELL;
-    const int border_off = zero_off + CELL + 512;   // after the zero cell and the k-step table
+    // LDS: [zero cell][ncell tile cells][k-step table 512 B][border table].  The zero cell sits at offset 0, so a dead tap's address is just
+    // (address & 0) (r3: one vector instruction less per fragment address than "zero_off + (... & mask)")
+    const int tab_off = (ncell + 1) * CELL;
+    const int border_off = tab_off + 512;
     const float inv_ws = 1.0f / (float)Ws, inv_hs = 1.0f / (float)Hs;
 
     // ---------------------------------------------------------------- this lane's output positions: one table entry each
@@ -206,18 +216,18 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
         int q;
         pb[j] = fdiv(P, p.cpc_in, inv_cpc, q);
         pe[j] = *reinterpret_cast<const i32x4*>(p.postab + 4 * q);
-        lbase[j] = (local + Ws + 1) * CELL;
+        lbase[j] = (local + Ws + 2) * CELL;     // (+ 1: the zero cell in front of the tile)
     }
     T3_TS(8)
     T3_TS(1)
     // ---------------------------------------------------------------- stage cells [P0 - Ws - 1, P0 + TILE_P + Ws + 1)
     {
         const int qd = tid % NQ, grp = tid / NQ;
-        if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + zero_off + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+        if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
         if (tid < 4 * (STEPS + 2)) {   // k-step table (see the k-loop): entry [s][g], two spare steps for the look-ahead
             const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
             // (zero-weight padding blocks, tap >= 9, test bit 31 of the mask word, which is never set: they read the zero cell)
-            reinterpret_cast<int2_*>(lds + zero_off + CELL)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16 - zero_off, tap < 9 ? tap : 31};
+            reinterpret_cast<int2_*>(lds + tab_off)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16, tap < 9 ? tap : 31};
         }
         // the border-bias table (16 border classes x NB*8 channels) goes to LDS: read from global memory in the epilogue, every one of
         // its loads waited -- vmcnt counts loads and stores alike -- for the previous block's output store as well (6.5 of 18 us per tile)
@@ -242,22 +252,22 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
                     const int i = i0 + u * NGRP;
                     if (i < ncell) {
                         if (S16) {           // the tensor already holds the operand type: eight channels, one 16-byte store
-                            *reinterpret_cast<f32x4*>(lds + i * CELL + qd * 16) = v[u];
+                            *reinterpret_cast<f32x4*>(lds + (i + 1) * CELL + qd * 16) = v[u];
                         } else if (NP == 2 && !F16) {   // bf16x3: the two leading bf16 parts
                             u32x2 pr[3];
                             split4(v[u], pr);
 #pragma unroll
-                            for (int pt = 0; pt < 2; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                            for (int pt = 0; pt < 2; ++pt) *reinterpret_cast<u32x2*>(lds + (i + 1) * CELL + pt * PART + qd * 8) = pr[pt];
                         } else if (F16) {
                             u32x2 pr[2];
                             split4_f16(v[u], pr);
 #pragma unroll
-                            for (int pt = 0; pt < 2; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                            for (int pt = 0; pt < 2; ++pt) *reinterpret_cast<u32x2*>(lds + (i + 1) * CELL + pt * PART + qd * 8) = pr[pt];
                         } else {
                             u32x2 pr[3];
                             split4(v[u], pr);
 #pragma unroll
-                            for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x2*>(lds + i * CELL + pt * PART + qd * 8) = pr[pt];
+                            for (int pt = 0; pt < 3; ++pt) *reinterpret_cast<u32x2*>(lds + (i + 1) * CELL + pt * PART + qd * 8) = pr[pt];
                         }
                     }
                 }
@@ -308,20 +318,20 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
         for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // This lane group's K block at k-step s: bi = 4 s + g -> (tap, channel block).  (tap, byte offset of that tap and block relative
-    // to the centre cell, minus zero_off) comes from a small LDS table written once per workgroup -- computing it in the loop cost
+    // to the centre cell) comes from a small LDS table written once per workgroup -- computing it in the loop cost
     // two integer divisions per step and, with a five-instruction select per fragment address, 146 vector instructions per k-step
     // against 45 MFMAs: the k-loop was bound by its own address arithmetic (11 us per tile where the MFMAs need 5).
     // A tap that leaves the sub-map or the tensor (mask bit clear; always for the zero-weight padding blocks, tap >= 9) reads the
-    // shared zero cell: address = zero_off + ((lbase + offz) & -(bit)).
-    const int2_* const ktab = reinterpret_cast<const int2_*>(lds + zero_off + CELL) + g;
+    // shared zero cell at LDS offset 0: address = (lbase + off) & -(bit).
+    const int2_* const ktab = reinterpret_cast<const int2_*>(lds + tab_off) + g;
     auto b_addr = [&](int j, int2_ e) {
         const int m = __builtin_amdgcn_sbfe(tmask[j], e[1], 1);      // 0 or -1
-        return zero_off + ((lbase[j] + e[0]) & m);
+        return (lbase[j] + e[0]) & m;
     };
 #define TLOADB(BR, ADDR)                                                                              \
     {                                                                                                 \
         const int ad_ = (ADDR);                                                                       \
-        _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) BR[pt] = *reinterpret_cast<const u32x4*>(lds + ad_ + pt * PART); \
+        _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) BR[pt] = t3_lds_read16(ad_ + pt * PART);                    \
     }
 #define TLOADA(AR, S)                                                                                 \
     {                                                                                                 \
@@ -543,14 +553,14 @@ __device__ __forceinline__ void pair_first_frags(const __amdgpu_buffer_rsrc_t ar
     for (int m = 0; m < MT; ++m) a[m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff, (m * (F16 ? 2 : 3)) * 1024, 0));
 }
 template <int NB, int MT, bool F16, int JT>
-__device__ __forceinline__ void pair_kloop(const char* lds, const int zero_off, const int2_* ktab, const __amdgpu_buffer_rsrc_t ars,
+__device__ __forceinline__ void pair_kloop(const char* lds, const int2_* ktab, const __amdgpu_buffer_rsrc_t ars,
                                            const int avoff, const u32x4 (&a_first)[MT], const int (&lbase)[JT], const int (&tmask)[JT],
                                            f32x4 (&acc)[JT][MT]) {
     constexpr int WP = F16 ? 2 : 3;                 // parts per weight fragment group as packed on the host (part 0 is used)
     constexpr int STEPS = (9 * NB + 3) / 4;
     auto b_addr = [&](int j, int2_ e) {
-        const int m = __builtin_amdgcn_sbfe(tmask[j], e[1], 1);      // 0 or -1: a dead tap reads the shared zero cell
-        return zero_off + ((lbase[j] + e[0]) & m);
+        const int m = __builtin_amdgcn_sbfe(tmask[j], e[1], 1);      // 0 or -1: a dead tap reads the shared zero cell at LDS offset 0
+        return (lbase[j] + e[0]) & m;
     };
     auto load_a = [&](u32x4 (&ar)[MT], int s) {
 #pragma unroll
@@ -566,7 +576,7 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int zero_off, 
     for (int m = 0; m < MT; ++m) a[0][m] = a_first[m];   // k-step 0's fragments: requested by the caller ahead of its barrier
 #pragma unroll
     for (int u = 1; u < APF; ++u) load_a(a[u], u < STEPS ? u : STEPS - 1);
-    bb[0] = *reinterpret_cast<const u32x4*>(lds + b_addr(0, e_c));
+    bb[0] = t3_lds_read16(b_addr(0, e_c));
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
         int2_ e_n = e_c;
@@ -576,8 +586,8 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int zero_off, 
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             const int t = s * JT + j;
-            if (j + 1 < JT) bb[(t + 1) & 1] = *reinterpret_cast<const u32x4*>(lds + b_addr(j + 1, e_c));
-            else if (s + 1 < STEPS) bb[(t + 1) & 1] = *reinterpret_cast<const u32x4*>(lds + b_addr(0, e_n));
+            if (j + 1 < JT) bb[(t + 1) & 1] = t3_lds_read16(b_addr(j + 1, e_c));
+            else if (s + 1 < STEPS) bb[(t + 1) & 1] = t3_lds_read16(b_addr(0, e_n));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -604,6 +614,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
     constexpr int NQ = NB, NGRP = NT / NQ;
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
+    t3_require_lds_base_zero(lds);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -616,9 +627,10 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
     }
     const int P0 = tile_id * TILE_P;
     const int n_in = TILE_P + 4 * halo, n_mid = TILE_P + 2 * halo;      // cells of the input tile / of y_i
-    const int mid_off = n_in * CELL;
-    const int zero_off = mid_off + n_mid * CELL;
-    const int border_off = zero_off + CELL + 512;   // [2][16 classes][NB*8] floats
+    // LDS: [zero cell][n_in input cells][n_mid cells of y_i][k-step table 512 B][border tables]
+    const int mid_off = (n_in + 1) * CELL;
+    const int tab_off = mid_off + n_mid * CELL;
+    const int border_off = tab_off + 512;           // [2][16 classes][NB*8] floats
     const float inv_cpc = 1.0f / (float)p.cpc_in;
 
     // ---- table entries of this lane's positions: outputs (conv_b) and intermediate cells (conv_a); both layers share the layout
@@ -643,10 +655,10 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
     // ---- stage cells [P0 - 2 halo, P0 + TILE_P + 2 halo), tables
     {
         const int qd = tid % NQ, grp = tid / NQ;
-        if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + zero_off + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+        if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
         if (tid < 4 * (STEPS + 2)) {
             const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
-            reinterpret_cast<int2_*>(lds + zero_off + CELL)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16 - zero_off, tap < 9 ? tap : 31};
+            reinterpret_cast<int2_*>(lds + tab_off)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16, tap < 9 ? tap : 31};
         }
         for (int t = tid; t < 2 * 32 * NB; t += NT) {
             const int which = t / (32 * NB), r = t - which * 32 * NB;
@@ -668,7 +680,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int i = i0 + u * NGRP;
-                    if (i < n_in) *reinterpret_cast<f32x4*>(lds + i * CELL + qd * 16) = v[u];
+                    if (i < n_in) *reinterpret_cast<f32x4*>(lds + (i + 1) * CELL + qd * 16) = v[u];
                 }
             }
         }
@@ -679,7 +691,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
     pair_first_frags<MT, F16>(ars_a, lane * 16, afirst);   // in flight across the barrier
     __syncthreads();
 
-    const int2_* const ktab = reinterpret_cast<const int2_*>(lds + zero_off + CELL) + g;
+    const int2_* const ktab = reinterpret_cast<const int2_*>(lds + tab_off) + g;
     float amax = 0.f;
     // ---------------------------------------------------------------- conv_i on the intermediate cells -> LDS
     {
@@ -688,7 +700,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
         for (int j = 0; j < JTA; ++j) {
             const int lm = (w * JTA + j) * 16 + pcol;
             const int Pm = P0 - halo + lm;
-            lbase[j] = (lm + halo) * CELL;                                   // its cell in the input tile
+            lbase[j] = (lm + halo + 1) * CELL;                               // its cell in the input tile (behind the zero cell)
             tmask[j] = (lm < n_mid && Pm >= 0 && Pm < p.total) ? pea[j] : 0;   // outside: no live tap, never read by conv_b either
         }
         f32x4 acc[JTA][MT];
@@ -698,7 +710,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         } else
-            pair_kloop<NB, MT, F16, JTA>(lds, zero_off, ktab, ars_a, lane * 16, afirst, lbase, tmask, acc);
+            pair_kloop<NB, MT, F16, JTA>(lds, ktab, ars_a, lane * 16, afirst, lbase, tmask, acc);
         pair_first_frags<MT, F16>(ars_b, lane * 16, afirst);   // conv_{i+1}'s first fragments: in flight across the epilogue and the barrier
 #pragma unroll
         for (int j = 0; j < JTA; ++j) {
@@ -739,7 +751,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         } else
-            pair_kloop<NB, MT, F16, JTB>(lds, zero_off, ktab, ars_b, lane * 16, afirst, lbase, tmask, acc);
+            pair_kloop<NB, MT, F16, JTB>(lds, ktab, ars_b, lane * 16, afirst, lbase, tmask, acc);
         char* const outp = reinterpret_cast<char*>(p.out);
 #pragma unroll
         for (int j = 0; j < JTB; ++j) {
@@ -752,7 +764,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
                 const int co0 = m * 16 + 4 * g;
                 if (co0 >= NB * 8) continue;
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(lds + border_off + ((16 + bmask) * (NB * 8) + co0) * 4);
-                const u32x2 rw = *reinterpret_cast<const u32x2*>(lds + (local + 2 * halo) * CELL + co0 * 2);   // x_{i-1} at this position
+                const u32x2 rw = *reinterpret_cast<const u32x2*>(lds + (local + 2 * halo + 1) * CELL + co0 * 2);   // x_{i-1} at this position
                 f32x4 rv;
                 if (F16) {
                     rv[0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[0] & 0xffffu));
