@@ -51,12 +51,80 @@ __device__ __forceinline__ void band_split4(f32x4 x, u32x2 (&out)[2]) {
 }  // namespace
 
 constexpr int BAND_NT = 4;   // position tiles per wave (half a band)
+#ifndef BAND_APF
+#define BAND_APF 3            // k-steps of weight-fragment look-ahead (A/B knob)
+#endif
+#ifndef BAND_KLOOP
+#define BAND_KLOOP 1          // 1: band_kloop<NTL> below (r3); 0: the macro loop it replaces (A/B knob)
+#endif
+
+namespace {
+// 32-bit LDS addresses for the fragment reads (res8_f16x3.hip, conv3x3_tile.hip): the kernel holds only dynamic LDS, which starts at address 0
+typedef const u32x4 __attribute__((address_space(3))) * band_lds_u32x4_ptr;
+typedef const int __attribute__((address_space(3))) * band_lds_i32_ptr;
+__device__ __forceinline__ u32x4 band_lds_read16(int addr) { return *reinterpret_cast<band_lds_u32x4_ptr>((unsigned)addr); }
+__device__ __forceinline__ int band_lds_read4(int addr) { return *reinterpret_cast<band_lds_i32_ptr>((unsigned)addr); }
+}  // namespace
+
+// (r3) The k-loop for a wave that owns NTL position tiles, NTL a compile-time constant.  The loop it replaces took the tile count at run time:
+// uniform branches around every fragment read and MFMA group, register copies where the paths met again, 64-bit vector adds for the weight
+// addresses and a vector add of the `lds` symbol per read -- 4.5 vector + as many scalar instructions per MFMA in the single-term form, where a
+// k-step is only 2 NTL MFMAs long: the loop was bound by its own bookkeeping (profiles/r03: vector pipe 47 % busy, matrix pipe 42 %).  Here a k-step
+// is MH x NP buffer loads at scalar offsets (BAND_APF steps ahead), NTL x NP LDS reads of the NEXT step's fragments at lbase[j] + koff
+// (one add each), one table word, and the MFMAs: chain-major for three-term products (res8_f16x3.hip, R8H_FENCE).
+template <int MH, int TERMS, int NTL>
+__device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, const int avoff, const int ktab_addr, const int (&lbase)[BAND_NT],
+                                           const int partb, const int ksteps, f32x4 (&acc)[MH][BAND_NT]) {
+    constexpr int NP = TERMS >= 3 ? 2 : 1;
+    constexpr int ASTEP_B = 2 * MH * 2 * 1024;           // bytes of weight fragments per k-step: [2 MH channel tiles][2 parts][64 lanes] x 16 B
+    constexpr int NA = BAND_APF + 1;
+    u32x4 a[NA][MH][NP], b[2][NTL][NP];
+    auto load_a = [&](u32x4 (&ar)[MH][NP], int st) {
+#pragma unroll
+        for (int m = 0; m < MH; ++m)
+#pragma unroll
+            for (int pt = 0; pt < NP; ++pt)
+                ar[m][pt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff + (m * 2 + pt) * 1024, st * ASTEP_B, 0));
+    };
+    auto load_b = [&](u32x4 (&br)[NP], int j, int koff) {
+        const int ad = lbase[j] + koff;
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt) br[pt] = band_lds_read16(ad + pt * partb);
+    };
+    int kc = band_lds_read4(ktab_addr);
+#pragma unroll
+    for (int u = 0; u < BAND_APF; ++u) load_a(a[u], min(u, ksteps - 1));
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) load_b(b[0][j], j, kc);
+    for (int s = 0; s < ksteps; s += NA) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            if (s + u >= ksteps) break;
+            const int kn = band_lds_read4(ktab_addr + 16 * (s + u + 1));     // (the table carries two spare steps)
+            load_a(a[(u + BAND_APF) % NA], min(s + u + BAND_APF, ksteps - 1));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                load_b(b[(u + 1) & 1][j], j, kn);          // the next step's fragment of this tile (past the end: a harmless re-read)
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 (&bc)[NP] = b[u & 1][j];
+#pragma unroll
+                for (int m = 0; m < MH; ++m) {
+                    if (TERMS >= 3) {
+                        BMF(a[u][m][NP - 1], bc[0], acc[m][j]);
+                        BMF(a[u][m][0], bc[NP - 1], acc[m][j]);
+                    }
+                    BMF(a[u][m][0], bc[0], acc[m][j]);
+                    if (TERMS >= 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
 #ifndef BAND_ORDER
 #define BAND_ORDER 1      // 1: chain-major MFMA order for three-term products (this file is compiled without hipcc's post-RA scheduler, which would
                           // deal the chains out again: cnn-trad-pool2 f32 5.42 -> 5.10 ms, cnn-trad-fpool3 6.59 -> 6.41; fences per chain instead: 7.04); 0: term-major
-#endif
-#ifndef BAND_APF
-#define BAND_APF 3            // k-steps of weight-fragment look-ahead (A/B knob)
 #endif
 
 // MH: channel tiles per wave (the layer has up to 2 MH); TERMS: 3 (two-part operands, fp32-accurate) or 1 (fp16 tensor in, one part)
@@ -165,6 +233,22 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
     for (int m = 0; m < MH; ++m)
 #pragma unroll
         for (int j = 0; j < BAND_NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if BAND_KLOOP
+    {
+        if ((unsigned)reinterpret_cast<uintptr_t>(lds) != 0u) __builtin_trap();     // the integer LDS addresses below assume dynamic LDS at 0
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(p.apk)), 0,
+                                                                             p.ksteps * (2 * MH * 2 * 1024), 0x00020000);
+        const int avoff = lane * 16 + (wm * MH) * 2 * 1024;      // this wave's first channel tile: [k-step][2 MH tiles][2 parts][64 lanes] x 16 B
+        const int ktab_addr = ktab_off + 4 * g;
+        switch (ntile) {
+            case 4: band_kloop<MH, TERMS, 4>(ars, avoff, ktab_addr, lbase, partb, p.ksteps, acc); break;
+            case 3: band_kloop<MH, TERMS, 3>(ars, avoff, ktab_addr, lbase, partb, p.ksteps, acc); break;
+            case 2: band_kloop<MH, TERMS, 2>(ars, avoff, ktab_addr, lbase, partb, p.ksteps, acc); break;
+            case 1: band_kloop<MH, TERMS, 1>(ars, avoff, ktab_addr, lbase, partb, p.ksteps, acc); break;
+            default: break;
+        }
+    }
+#else
     const u32x4* A = reinterpret_cast<const u32x4*>(p.apk) + (size_t)(wm * MH) * 2 * 64 + lane;   // [k-step][2 MH tiles][2 parts][64]
     const int* ktab = reinterpret_cast<const int*>(lds + ktab_off) + g;
     constexpr int ASTEP = 2 * MH * 2 * 64;   // u32x4 per k-step
@@ -257,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
 #undef BTERM1
 #undef BCHAIN
 #undef BSTEP
+#endif   // BAND_KLOOP
 
     BAND_TS(3)
     // ---------------------------------------------------------------- epilogue: bias, ReLU, channels-last fp32 stores
