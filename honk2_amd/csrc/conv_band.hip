@@ -21,7 +21,7 @@
 //   * K order (tap, 8-channel block), four blocks per v_mfma_f32_16x16x32_f16 (one per 16-lane group); a k-step's (tap, block) of
 //     each lane group is a byte offset from a table in LDS.  Weights: fp16 parts scaled by 2^S in fragment order from L2 (shared by
 //     every workgroup), one k-step ahead.
-//   * Waves 2 x 2: wave (wm, wn) owns half of the channel tiles (MH = 2 or 3) and half of the band's position tiles (<= 4): per
+//   * Waves 2 x 2: wave (wm, wn) owns half of the channel tiles (MH = 2 or 3) and half of the band's position tiles (<= 4; <= 8 with fp16 tensors): per
 //     k-step MH x NP weight fragments (vector memory) + NT x NP activation fragments (LDS) feed MH x NT x terms MFMAs -- the split
 //     that keeps both operand paths below the matrix pipe's time for three-term products.
 #include "kws_internal.h"
@@ -50,12 +50,14 @@ __device__ __forceinline__ void band_split4(f32x4 x, u32x2 (&out)[2]) {
 #define BMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
 }  // namespace
 
-constexpr int BAND_NT = 4;   // position tiles per wave (half a band)
+constexpr int BAND_NT = 4;    // position tiles per wave (half a band): two-part operands (fp32-accurate products)
+constexpr int BAND_NT1 = 8;   // ... single-part fp16 tensors: half the LDS per row, so twice the rows per band -- and every weight fragment a wave loads
+                              // meets up to eight position tiles instead of four (r3: the weight stream from L2 was the kernel's largest cost, see DESIGN)
 #ifndef BAND_APF
 #define BAND_APF 3            // k-steps of weight-fragment look-ahead (A/B knob)
 #endif
-#ifndef BAND_KLOOP
-#define BAND_KLOOP 1          // 1: band_kloop<NTL> below (r3); 0: the macro loop it replaces (A/B knob)
+#ifndef BAND_ABLATE
+#define BAND_ABLATE 0        // timing experiments (results wrong): 1 no LDS fragment reads in the k-loop, 2 no weight-fragment loads
 #endif
 
 namespace {
@@ -72,9 +74,9 @@ __device__ __forceinline__ int band_lds_read4(int addr) { return *reinterpret_ca
 // k-step is only 2 NTL MFMAs long: the loop was bound by its own bookkeeping (profiles/r03: vector pipe 47 % busy, matrix pipe 42 %).  Here a k-step
 // is MH x NP buffer loads at scalar offsets (BAND_APF steps ahead), NTL x NP LDS reads of the NEXT step's fragments at lbase[j] + koff
 // (one add each), one table word, and the MFMAs: chain-major for three-term products (res8_f16x3.hip, R8H_FENCE).
-template <int MH, int TERMS, int NTL>
-__device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, const int avoff, const int ktab_addr, const int (&lbase)[BAND_NT],
-                                           const int partb, const int ksteps, f32x4 (&acc)[MH][BAND_NT]) {
+template <int MH, int TERMS, int NTL, int NT>
+__device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, const int avoff, const int ktab_addr, const int (&lbase)[NT],
+                                           const int partb, const int ksteps, f32x4 (&acc)[MH][NT]) {
     constexpr int NP = TERMS >= 3 ? 2 : 1;
     constexpr int ASTEP_B = 2 * MH * 2 * 1024;           // bytes of weight fragments per k-step: [2 MH channel tiles][2 parts][64 lanes] x 16 B
     constexpr int NA = BAND_APF + 1;
@@ -101,11 +103,12 @@ __device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, con
         for (int u = 0; u < NA; ++u) {
             if (s + u >= ksteps) break;
             const int kn = band_lds_read4(ktab_addr + 16 * (s + u + 1));     // (the table carries two spare steps)
-            load_a(a[(u + BAND_APF) % NA], min(s + u + BAND_APF, ksteps - 1));
+            if (!(BAND_ABLATE & 2)) load_a(a[(u + BAND_APF) % NA], min(s + u + BAND_APF, ksteps - 1));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NTL; ++j) {
-                load_b(b[(u + 1) & 1][j], j, kn);          // the next step's fragment of this tile (past the end: a harmless re-read)
+                if (!(BAND_ABLATE & 1)) load_b(b[(u + 1) & 1][j], j, kn);          // the next step's fragment of this tile (past the end: a harmless re-read)
+                else b[(u + 1) & 1][j][0] = b[u & 1][j][0], b[(u + 1) & 1][j][NP - 1] = b[u & 1][j][NP - 1];
                 __builtin_amdgcn_sched_barrier(0);
                 const u32x4 (&bc)[NP] = b[u & 1][j];
 #pragma unroll
@@ -122,13 +125,9 @@ __device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, con
         }
     }
 }
-#ifndef BAND_ORDER
-#define BAND_ORDER 1      // 1: chain-major MFMA order for three-term products (this file is compiled without hipcc's post-RA scheduler, which would
-                          // deal the chains out again: cnn-trad-pool2 f32 5.42 -> 5.10 ms, cnn-trad-fpool3 6.59 -> 6.41; fences per chain instead: 7.04); 0: term-major
-#endif
 
 // MH: channel tiles per wave (the layer has up to 2 MH); TERMS: 3 (two-part operands, fp32-accurate) or 1 (fp16 tensor in, one part)
-template <int MH, int TERMS>
+template <int MH, int TERMS, int NT>
 __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
     constexpr int NP = TERMS >= 3 ? 2 : 1;
     constexpr bool S16 = TERMS == 1;
@@ -213,10 +212,10 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
 
     // this lane's output positions: tile t = wn * nth + j of the layer's position table (conv_band_plan), entry {cell, oy << 16 | ox}
     const int nth = (p.ntiles + 1) >> 1;
-    int lbase[BAND_NT], opos[BAND_NT];
+    int lbase[NT], opos[NT];
     const int ntile = min(nth, max(0, p.ntiles - wn * nth));     // tiles of this wave (uniform)
 #pragma unroll
-    for (int j = 0; j < BAND_NT; ++j) {
+    for (int j = 0; j < NT; ++j) {
         const int t = min(wn * nth + j, p.ntiles - 1);
         const int cellv = p.postab[(t * 16 + pcol) * 2], yx = p.postab[(t * 16 + pcol) * 2 + 1];
         const int oy = yx >> 16, ox = yx & 0xffff;
@@ -228,120 +227,24 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
     BAND_TS(2)
 
     // ---------------------------------------------------------------- k-loop
-    f32x4 acc[MH][BAND_NT];
+    f32x4 acc[MH][NT];
 #pragma unroll
     for (int m = 0; m < MH; ++m)
 #pragma unroll
-        for (int j = 0; j < BAND_NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#if BAND_KLOOP
+        for (int j = 0; j < NT; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
         if ((unsigned)reinterpret_cast<uintptr_t>(lds) != 0u) __builtin_trap();     // the integer LDS addresses below assume dynamic LDS at 0
         const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(p.apk)), 0,
                                                                              p.ksteps * (2 * MH * 2 * 1024), 0x00020000);
         const int avoff = lane * 16 + (wm * MH) * 2 * 1024;      // this wave's first channel tile: [k-step][2 MH tiles][2 parts][64 lanes] x 16 B
         const int ktab_addr = ktab_off + 4 * g;
-        switch (ntile) {
-            case 4: band_kloop<MH, TERMS, 4>(ars, avoff, ktab_addr, lbase, partb, p.ksteps, acc); break;
-            case 3: band_kloop<MH, TERMS, 3>(ars, avoff, ktab_addr, lbase, partb, p.ksteps, acc); break;
-            case 2: band_kloop<MH, TERMS, 2>(ars, avoff, ktab_addr, lbase, partb, p.ksteps, acc); break;
-            case 1: band_kloop<MH, TERMS, 1>(ars, avoff, ktab_addr, lbase, partb, p.ksteps, acc); break;
+#define BAND_CASE(N) case N: if (N <= NT) band_kloop<MH, TERMS, (N <= NT ? N : 1), NT>(ars, avoff, ktab_addr, lbase, partb, p.ksteps, acc); break;
+        switch (ntile) {      // the wave's tile count becomes a compile-time constant of its k-loop
+            BAND_CASE(8) BAND_CASE(7) BAND_CASE(6) BAND_CASE(5) BAND_CASE(4) BAND_CASE(3) BAND_CASE(2) BAND_CASE(1)
             default: break;
         }
+#undef BAND_CASE
     }
-#else
-    const u32x4* A = reinterpret_cast<const u32x4*>(p.apk) + (size_t)(wm * MH) * 2 * 64 + lane;   // [k-step][2 MH tiles][2 parts][64]
-    const int* ktab = reinterpret_cast<const int*>(lds + ktab_off) + g;
-    constexpr int ASTEP = 2 * MH * 2 * 64;   // u32x4 per k-step
-
-#define BLOADA(AR, S)                                                                                      \
-    {                                                                                                      \
-        _Pragma("unroll") for (int m = 0; m < MH; ++m)                                                     \
-            _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) AR[m][pt] = A[(size_t)(S) * ASTEP + (m * 2 + pt) * 64]; \
-    }
-#define BLOADB(BR, J, KOFF)                                                                                \
-    {                                                                                                      \
-        const int ad_ = lbase[J] + (KOFF);                                                                 \
-        _Pragma("unroll") for (int pt = 0; pt < NP; ++pt) BR[pt] = *reinterpret_cast<const u32x4*>(lds + pt * partb + ad_); \
-    }
-    // one term of a tile pair: four independent accumulator chains (two channel tiles x two position tiles; MH = 3: six) -- with one
-    // tile at a time an accumulator came round again after one other MFMA, inside the matrix pipe's own latency
-#define BTERM2(PA, PB, AR, B0, B1, J)                                                                      \
-    {                                                                                                      \
-        _Pragma("unroll") for (int m = 0; m < MH; ++m) BMF(AR[m][PA], B0[PB], acc[m][J]);                  \
-        _Pragma("unroll") for (int m = 0; m < MH; ++m) BMF(AR[m][PA], B1[PB], acc[m][(J) + 1]);            \
-    }
-#define BTERM1(PA, PB, AR, B0, J)                                                                          \
-    {                                                                                                      \
-        _Pragma("unroll") for (int m = 0; m < MH; ++m) BMF(AR[m][PA], B0[PB], acc[m][J]);                  \
-    }
-    // chain-major form (BAND_ORDER 1): the three terms of an accumulator back to back (the dependent MFMA takes its C from the one before it)
-#define BCHAIN(AR, B0, J)                                                                                  \
-    {                                                                                                      \
-        _Pragma("unroll") for (int m = 0; m < MH; ++m) {                                                   \
-            BMF(AR[m][NP - 1], B0[0], acc[m][J]);                                                          \
-            BMF(AR[m][0], B0[NP - 1], acc[m][J]);                                                          \
-            BMF(AR[m][0], B0[0], acc[m][J]);                                                               \
-        }                                                                                                  \
-    }
-    // one k-step: B fragments one tile PAIR ahead; (bq0, bq1) hold tiles 0, 1 on entry and tiles 0, 1 of the next step (offset KNEXT)
-    // on exit (BAND_NT / 2 pairs per step is even: the buffers keep their roles from step to step)
-#define BSTEP(AR, KCUR, KNEXT)                                                                             \
-    {                                                                                                      \
-        _Pragma("unroll") for (int jp = 0; jp < BAND_NT; jp += 2) {                                        \
-            u32x4 (&c0_)[NP] = (jp & 2) ? bq2 : bq0;                                                       \
-            u32x4 (&c1_)[NP] = (jp & 2) ? bq3 : bq1;                                                       \
-            u32x4 (&n0_)[NP] = (jp & 2) ? bq0 : bq2;                                                       \
-            u32x4 (&n1_)[NP] = (jp & 2) ? bq1 : bq3;                                                       \
-            if (jp + 2 < BAND_NT) {                                                                        \
-                if (jp + 2 < ntile) BLOADB(n0_, jp + 2, KCUR)                                              \
-                if (jp + 3 < ntile) BLOADB(n1_, jp + 3, KCUR)                                              \
-            } else {                                                                                       \
-                BLOADB(n0_, 0, KNEXT)                                                                      \
-                if (1 < ntile) BLOADB(n1_, 1, KNEXT)                                                       \
-            }                                                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                             \
-            if (BAND_ORDER == 1 && TERMS >= 3) {                                                           \
-                if (jp < ntile) BCHAIN(AR, c0_, jp)                                                        \
-                if (jp + 1 < ntile) BCHAIN(AR, c1_, jp + 1)                                                \
-            } else if (jp + 1 < ntile) {                                                                   \
-                if (TERMS >= 3) { BTERM2(1, 0, AR, c0_, c1_, jp) BTERM2(0, 1, AR, c0_, c1_, jp) }          \
-                BTERM2(0, 0, AR, c0_, c1_, jp)                                                             \
-            } else if (jp < ntile) {                                                                       \
-                if (TERMS >= 3) { BTERM1(1, 0, AR, c0_, jp) BTERM1(0, 1, AR, c0_, jp) }                    \
-                BTERM1(0, 0, AR, c0_, jp)                                                                  \
-            }                                                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                             \
-        }                                                                                                  \
-    }
-    static_assert(BAND_NT % 4 == 0, "fragment buffers keep their roles");
-    // Weight fragments are requested BAND_APF k-steps ahead: a k-step is only 6 - 27 MFMAs (100 - 430 clocks) long, less than an L2
-    // round trip, and the fragments of a layer (320 - 640 KB) do not stay in the CU's L1.
-    u32x4 a[BAND_APF + 1][MH][NP], bq0[NP], bq1[NP], bq2[NP], bq3[NP];
-    if (ntile > 0) {
-        int kc = ktab[0];
-#pragma unroll
-        for (int u = 0; u < BAND_APF; ++u) BLOADA(a[u], min(u, p.ksteps - 1))
-        BLOADB(bq0, 0, kc)
-        BLOADB(bq1, 1, kc)
-        for (int s = 0; s < p.ksteps; s += BAND_APF + 1) {
-#pragma unroll
-            for (int u = 0; u <= BAND_APF; ++u) {
-                if (s + u >= p.ksteps) break;
-                const int kn = ktab[4 * (s + u + 1)];
-                BLOADA(a[(u + BAND_APF) % (BAND_APF + 1)], min(s + u + BAND_APF, p.ksteps - 1))
-                __builtin_amdgcn_sched_barrier(0);
-                BSTEP(a[u], kc, kn)
-                kc = kn;
-            }
-        }
-    }
-#undef BLOADA
-#undef BLOADB
-#undef BTERM2
-#undef BTERM1
-#undef BCHAIN
-#undef BSTEP
-#endif   // BAND_KLOOP
 
     BAND_TS(3)
     // ---------------------------------------------------------------- epilogue: bias, ReLU, channels-last fp32 stores
@@ -355,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = co0 + r < p.Cout ? p.bias[co0 + r] : 0.f;
 #pragma unroll
-        for (int j = 0; j < BAND_NT; ++j) {
+        for (int j = 0; j < NT; ++j) {
             if (j >= ntile || opos[j] < 0) continue;
             f32x4 v;
 #pragma unroll
@@ -410,10 +313,12 @@ static int band_tiles(int R, int Wo, int Wl, std::vector<int>* tab) {
     return (int)nt;
 }
 
-// Rows per band R and LDS row stride Wl: the band must fit half a CU's LDS with two-part operands and 2 x BAND_NT position tiles;
+// Rows per band R and LDS row stride Wl: the band must fit half a CU's LDS with `parts` operand parts (2: fp32-accurate products, 1: fp16 tensors)
+// and 2 x BAND_NT (2 x BAND_NT1 for one part) position tiles;
 // among those, the best share of useful MFMA slots (tile fill x rows covered, halo rows re-staged by every band counted against
 // small R).  false: the layer does not fit this kernel.
-bool conv_band_plan(int Cin, int Cout, int H, int W, int kh, int kw, BandPlan& out) {
+bool conv_band_plan(int Cin, int Cout, int H, int W, int kh, int kw, int parts, BandPlan& out) {
+    const int max_nt = 2 * (parts == 1 ? BAND_NT1 : BAND_NT);
     const int Cpi = (Cin + 15) / 16 * 16, Ho = H - kh + 1, Wo = W - kw + 1, mh = conv_band_mh(Cout);
     out = BandPlan{};
     if (Cin < 16 || (mh != 2 && mh != 3) || Ho < 1 || Wo < 1 || Wo > 0xffff) return false;
@@ -422,9 +327,9 @@ bool conv_band_plan(int Cin, int Cout, int H, int W, int kh, int kw, BandPlan& o
         bool any = false;
         for (int Wl = W; Wl < W + 16; ++Wl) {
             const int PS = ((R + kh - 1) * Wl + 15) / 16 * 16;
-            if (conv_band_lds_bytes(Cpi, kh, kw, PS, 2) > 80 * 1024 - 256) continue;
+            if (conv_band_lds_bytes(Cpi, kh, kw, PS, parts) > 80 * 1024 - 256) continue;
             const int nt = band_tiles(R, Wo, Wl, nullptr);
-            if (nt > 2 * BAND_NT) continue;
+            if (nt > max_nt) continue;
             any = true;
             const int nb = (Ho + R - 1) / R, slots = 2 * ((nt + 1) / 2);
             const double eff = (double)(Ho * Wo) / ((double)nb * slots * 16) * ((double)R / (R + 0.25 * (kh - 1)));
@@ -433,7 +338,7 @@ bool conv_band_plan(int Cin, int Cout, int H, int W, int kh, int kw, BandPlan& o
                 out.R = R; out.Wl = Wl; out.PS = PS; out.ntiles = nt;
             }
         }
-        if (!any && R * Wo > 16 * 2 * BAND_NT) break;
+        if (!any && R * Wo > 16 * max_nt) break;
     }
     if (out.R == 0) return false;
     band_tiles(out.R, Wo, out.Wl, &out.tab);
@@ -462,10 +367,10 @@ void pack_conv_band_weights(int Cin, int Cout, int kh, int kw, const float* w, f
             }
 }
 
-template <int MH, int TERMS>
+template <int MH, int TERMS, int NT>
 static hipError_t launch_band_k(const BandConvParams& p, hipStream_t s) {
     const size_t lds = conv_band_lds_bytes(p.Cpi, p.kh, p.kw, p.PS, TERMS >= 3 ? 2 : 1);
-    auto k = conv_band_kernel<MH, TERMS>;
+    auto k = conv_band_kernel<MH, TERMS, NT>;
     static DeviceOnce attr_once;   // per instantiation: allow > 64 KB of dynamic LDS
     if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -478,12 +383,14 @@ static hipError_t launch_band_k(const BandConvParams& p, hipStream_t s) {
 hipError_t launch_conv_band(const BandConvParams& p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     const int mh = conv_band_mh(p.Cout);
-    if (p.R < 1 || p.Cpi % 16 || p.Cpo % 16 || p.Cpo < p.Cout || p.Cpo > 32 * mh || p.ntiles < 1 || p.ntiles > 2 * BAND_NT ||
+    const int parts = p.terms == 3 ? 2 : 1;
+    if (p.R < 1 || p.Cpi % 16 || p.Cpo % 16 || p.Cpo < p.Cout || p.Cpo > 32 * mh || p.ntiles < 1 || p.ntiles > 2 * (parts == 1 ? BAND_NT1 : BAND_NT) ||
         p.Wl < p.W || p.PS % 16 || p.PS < (p.R + p.kh - 1) * p.Wl || !p.postab || (p.terms != 3 && p.terms != 1) ||
-        conv_band_lds_bytes(p.Cpi, p.kh, p.kw, p.PS, 2) > 160 * 1024 - 512)
+        conv_band_lds_bytes(p.Cpi, p.kh, p.kw, p.PS, parts) > 160 * 1024 - 512)
         return hipErrorInvalidValue;
-    if (mh == 2) return p.terms == 3 ? launch_band_k<2, 3>(p, s) : launch_band_k<2, 1>(p, s);
-    return p.terms == 3 ? launch_band_k<3, 3>(p, s) : launch_band_k<3, 1>(p, s);
+    if (p.terms == 3) return mh == 2 ? launch_band_k<2, 3, BAND_NT>(p, s) : launch_band_k<3, 3, BAND_NT>(p, s);
+    if (p.ntiles <= 2 * BAND_NT) return mh == 2 ? launch_band_k<2, 1, BAND_NT>(p, s) : launch_band_k<3, 1, BAND_NT>(p, s);
+    return mh == 2 ? launch_band_k<2, 1, BAND_NT1>(p, s) : launch_band_k<3, 1, BAND_NT1>(p, s);
 }
 
 }  // namespace kws

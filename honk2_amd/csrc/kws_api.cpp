@@ -122,6 +122,7 @@ struct kws_handle {
     // "cnn_band" plan (fp16-part modes): conv_0 writes channels-last cells, conv_1 runs in conv_band.hip, the first Linear reads
     // its channels-last output through column-permuted weights (clin0_cl)
     int cnn_band_R = 0;                    // output rows per band of conv_1, 0: plan not available
+    int cnn_band_parts = 2;                // operand parts the band plan was sized for (1: fp16 tensors only)
     bool cnn_in1 = false;                  // conv_0 runs in conv_in1.hip (LDS image of the clip) in the channels-last plans
     bool cnn_cl1 = false;                  // single-conv model: conv_in1 -> clin0_cl ("cnn_in1" plan)
     int cl_last[3] = {0, 0, 0};            // (channels, positions, channels per cell) of the tensor the first Linear reads
@@ -348,7 +349,9 @@ int build_cnn(kws_handle* h) {
         d.pool_kh[1] * d.pool_kw[1] == 1 && d.pool_kh[0] * d.pool_kw[0] <= 16 && !h->clin.empty()) {
         const int C0 = h->cnn_shape[1][0], H1 = h->cnn_shape[1][1], W1 = h->cnn_shape[1][2];
         const int C1 = d.conv[1].out_channels;
-        if (conv_band_plan(C0, C1, H1, W1, d.conv[1].kernel_h, d.conv[1].kernel_w, h->cnn_band)) {
+        // (fp16 tensors -- KWS_DTYPE_F16 -- hold one operand part: bands of twice the rows; the guard's second pass does not use this plan)
+        h->cnn_band_parts = d.dtype == KWS_DTYPE_F16 ? 1 : 2;
+        if (conv_band_plan(C0, C1, H1, W1, d.conv[1].kernel_h, d.conv[1].kernel_w, h->cnn_band_parts, h->cnn_band)) {
             int rcu = h->cnn_band_tab.upload(h->cnn_band.tab.data(), h->cnn_band.tab.size() * sizeof(int));
             if (rcu) return rcu;
             h->cnn_band_R = h->cnn_band.R;
@@ -884,7 +887,7 @@ int launch_conv_auto(const ConvLayer& L, ConvGeom g, ConvArgs a, int nb, float* 
 bool cnn_band_plan(const kws_handle* h, int mode) {
     int f16, terms;
     decode_mode(mode, f16, terms);
-    return h->cnn_band_R > 0 && f16 && h->cconv[0].use_x && h->clin0_cl.use_x && h->cconv[1].apk_band.p != nullptr;
+    return h->cnn_band_R > 0 && f16 && (h->cnn_band_parts == 2 || terms == 1) && h->cconv[0].use_x && h->clin0_cl.use_x && h->cconv[1].apk_band.p != nullptr;
 }
 // single-conv models: conv_0 from the LDS image (conv_in1.hip), channels-last cells straight into the permuted Linear
 bool cnn_in1_plan(const kws_handle* h, int mode) {

@@ -383,7 +383,7 @@ struct BandPlan {
     int R = 0, Wl = 0, PS = 0, ntiles = 0;
     std::vector<int> tab;
 };
-bool conv_band_plan(int Cin, int Cout, int H, int W, int kh, int kw, BandPlan& out);   // false: layer not supported
+bool conv_band_plan(int Cin, int Cout, int H, int W, int kh, int kw, int parts, BandPlan& out);   // parts: 2 fp32-accurate products, 1 fp16 tensors; false: layer not supported
 size_t conv_band_lds_bytes(int Cpi, int kh, int kw, int PS, int parts);
 void pack_conv_band_weights(int Cin, int Cout, int kh, int kw, const float* w, float scale, std::vector<unsigned short>& dst);
 hipError_t launch_conv_band(const BandConvParams& p, hipStream_t s);
