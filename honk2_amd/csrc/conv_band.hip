@@ -50,9 +50,10 @@ __device__ __forceinline__ void band_split4(f32x4 x, u32x2 (&out)[2]) {
 #define BMF(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
 }  // namespace
 
-constexpr int BAND_NT = 4;    // position tiles per wave (half a band): two-part operands (fp32-accurate products)
-constexpr int BAND_NT1 = 8;   // ... single-part fp16 tensors: half the LDS per row, so twice the rows per band -- and every weight fragment a wave loads
-                              // meets up to eight position tiles instead of four (r3: the weight stream from L2 was the kernel's largest cost, see DESIGN)
+constexpr int BAND_NT = 4;    // position tiles per wave (half a band) of the narrow instantiation
+constexpr int BAND_NT1 = 8;   // ... of the wide one, for bands of more than eight tiles: every weight fragment a wave loads meets up to eight position tiles
+                              // instead of four (r3: the weight stream from L2 was the kernel's largest cost, see DESIGN); fp16 tensors hold one operand part, half the
+                              // LDS per row, and get there with twice the rows per band
 #ifndef BAND_APF
 #define BAND_APF 3            // k-steps of weight-fragment look-ahead (A/B knob)
 #endif
@@ -80,7 +81,12 @@ __device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, con
     constexpr int NP = TERMS >= 3 ? 2 : 1;
     constexpr int ASTEP_B = 2 * MH * 2 * 1024;           // bytes of weight fragments per k-step: [2 MH channel tiles][2 parts][64 lanes] x 16 B
     constexpr int NA = BAND_APF + 1;
-    u32x4 a[NA][MH][NP], b[2][NTL][NP];
+    // B fragments: single-term products finish a tile in MH MFMAs -- less than an LDS round trip -- so the whole NEXT k-step's fragments are in
+    // flight (two sets of NTL); three-term products take 3 MH MFMAs per tile and look one tile ahead (two buffers: the registers buy 2 x 8 tiles)
+    constexpr bool STEP_AHEAD = TERMS < 3;
+    constexpr int NBUF = STEP_AHEAD ? 2 * NTL : 2;
+    static_assert((NA * NTL) % 2 == 0, "the two-buffer ring keeps its phase from block to block");
+    u32x4 a[NA][MH][NP], b[NBUF][NP];
     auto load_a = [&](u32x4 (&ar)[MH][NP], int st) {
 #pragma unroll
         for (int m = 0; m < MH; ++m)
@@ -96,8 +102,11 @@ __device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, con
     int kc = band_lds_read4(ktab_addr);
 #pragma unroll
     for (int u = 0; u < BAND_APF; ++u) load_a(a[u], min(u, ksteps - 1));
+    if (STEP_AHEAD) {
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) load_b(b[0][j], j, kc);
+        for (int j = 0; j < NTL; ++j) load_b(b[j], j, kc);
+    } else
+        load_b(b[0], 0, kc);
     for (int s = 0; s < ksteps; s += NA) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
@@ -107,10 +116,17 @@ __device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, con
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NTL; ++j) {
-                if (!(BAND_ABLATE & 1)) load_b(b[(u + 1) & 1][j], j, kn);          // the next step's fragment of this tile (past the end: a harmless re-read)
-                else b[(u + 1) & 1][j][0] = b[u & 1][j][0], b[(u + 1) & 1][j][NP - 1] = b[u & 1][j][NP - 1];
+                const int t = u * NTL + j;                    // position in the unrolled block
+                const int cur = STEP_AHEAD ? (u & 1) * NTL + j : (t & 1);
+                const int nxt = STEP_AHEAD ? ((u + 1) & 1) * NTL + j : ((t + 1) & 1);
+                if (!(BAND_ABLATE & 1)) {
+                    if (STEP_AHEAD) load_b(b[nxt], j, kn);      // the next step's fragment of this tile (past the end: a harmless re-read)
+                    else if (j + 1 < NTL) load_b(b[nxt], j + 1, kc);
+                    else load_b(b[nxt], 0, kn);
+                } else
+                    b[nxt][0] = b[cur][0], b[nxt][NP - 1] = b[cur][NP - 1];
                 __builtin_amdgcn_sched_barrier(0);
-                const u32x4 (&bc)[NP] = b[u & 1][j];
+                const u32x4 (&bc)[NP] = b[cur];
 #pragma unroll
                 for (int m = 0; m < MH; ++m) {
                     if (TERMS >= 3) {
@@ -122,6 +138,7 @@ __device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, con
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            kc = kn;
         }
     }
 }
@@ -318,7 +335,7 @@ static int band_tiles(int R, int Wo, int Wl, std::vector<int>* tab) {
 // among those, the best share of useful MFMA slots (tile fill x rows covered, halo rows re-staged by every band counted against
 // small R).  false: the layer does not fit this kernel.
 bool conv_band_plan(int Cin, int Cout, int H, int W, int kh, int kw, int parts, BandPlan& out) {
-    const int max_nt = 2 * (parts == 1 ? BAND_NT1 : BAND_NT);
+    const int max_nt = 2 * BAND_NT1;
     const int Cpi = (Cin + 15) / 16 * 16, Ho = H - kh + 1, Wo = W - kw + 1, mh = conv_band_mh(Cout);
     out = BandPlan{};
     if (Cin < 16 || (mh != 2 && mh != 3) || Ho < 1 || Wo < 1 || Wo > 0xffff) return false;
@@ -384,12 +401,16 @@ hipError_t launch_conv_band(const BandConvParams& p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     const int mh = conv_band_mh(p.Cout);
     const int parts = p.terms == 3 ? 2 : 1;
-    if (p.R < 1 || p.Cpi % 16 || p.Cpo % 16 || p.Cpo < p.Cout || p.Cpo > 32 * mh || p.ntiles < 1 || p.ntiles > 2 * (parts == 1 ? BAND_NT1 : BAND_NT) ||
+    if (p.R < 1 || p.Cpi % 16 || p.Cpo % 16 || p.Cpo < p.Cout || p.Cpo > 32 * mh || p.ntiles < 1 || p.ntiles > 2 * BAND_NT1 ||
         p.Wl < p.W || p.PS % 16 || p.PS < (p.R + p.kh - 1) * p.Wl || !p.postab || (p.terms != 3 && p.terms != 1) ||
         conv_band_lds_bytes(p.Cpi, p.kh, p.kw, p.PS, parts) > 160 * 1024 - 512)
         return hipErrorInvalidValue;
-    if (p.terms == 3) return mh == 2 ? launch_band_k<2, 3, BAND_NT>(p, s) : launch_band_k<3, 3, BAND_NT>(p, s);
-    if (p.ntiles <= 2 * BAND_NT) return mh == 2 ? launch_band_k<2, 1, BAND_NT>(p, s) : launch_band_k<3, 1, BAND_NT>(p, s);
+    const bool wide = p.ntiles > 2 * BAND_NT;      // more than four tiles per wave
+    if (p.terms == 3) {
+        if (!wide) return mh == 2 ? launch_band_k<2, 3, BAND_NT>(p, s) : launch_band_k<3, 3, BAND_NT>(p, s);
+        return mh == 2 ? launch_band_k<2, 3, BAND_NT1>(p, s) : launch_band_k<3, 3, BAND_NT1>(p, s);
+    }
+    if (!wide) return mh == 2 ? launch_band_k<2, 1, BAND_NT>(p, s) : launch_band_k<3, 1, BAND_NT>(p, s);
     return mh == 2 ? launch_band_k<2, 1, BAND_NT1>(p, s) : launch_band_k<3, 1, BAND_NT1>(p, s);
 }
 
