@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
     const u32x4* A = reinterpret_cast<const u32x4*>(p.apk) + lane;   // [group][k-step][MH][2 parts][64]
     const int kstep_b = 4 * RS * 2;              // bytes per k-step (four feature rows)
     float amax = 0.f;
+    const float pinf = opaque_pinf();
 
     for (int cg = 0; cg < ngroup; ++cg) {
         u32x4 a[KS][MH][NP];
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
 #pragma unroll
                 for (int m = 0; m < MH; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) best[m][r] = fmaxf(best[m][r], acc[m][r]);
+                    for (int r = 0; r < 4; ++r) best[m][r] = vmax_f32(best[m][r], acc[m][r], pinf);
             }
             if (ps >= npq) continue;
             const size_t cell = ((size_t)b * npq + ps) * p.Cp;

@@ -87,6 +87,16 @@ struct RangeGate {
 };
 constexpr float KWS_RANGE_LIMIT = 32768.f;
 #if defined(__HIPCC__)
+// max(a, b) as ONE instruction: v_med3_f32(a, b, +inf) with the +inf in a register the compiler cannot see through (opaque_pinf(): call it once per
+// kernel, outside the loops).  fmaxf() itself compiles to three instructions -- hipcc canonicalises both operands first (v_max x, x, x) in case one is a
+// signalling NaN -- 48 instead of 16 per window member in the MaxPool reductions; fmed3 with a CONSTANT +inf is folded back into that fmax.  A NaN operand
+// loses, as with fmaxf.  (Not inline asm: the hazard recogniser pads nothing for an asm that reads an MFMA result.)
+__device__ __forceinline__ float opaque_pinf() {
+    float v = __builtin_inff();
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float vmax_f32(float a, float b, float pinf) { return __builtin_amdgcn_fmed3f(a, b, pinf); }
 __device__ __forceinline__ bool range_gate_closed(const RangeGate& rg) {
     return rg.gated && rg.flag && __builtin_nontemporal_load(rg.flag) == 0u;
 }

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
 
+    const float pinf = opaque_pinf();   // (vmax_f32)
     f32x4 best[MULTI ? MT : 1];   // running maximum over the window members
 #pragma unroll
     for (int m = 0; m < (MULTI ? MT : 1); ++m) best[m] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
                 for (int j = 0; j < 4; ++j)
                     if (j < ntile)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) best[MULTI ? m : 0][r] = fmaxf(best[MULTI ? m : 0][r], acc[m][j][r]);
+                        for (int r = 0; r < 4; ++r) best[MULTI ? m : 0][r] = vmax_f32(best[MULTI ? m : 0][r], acc[m][j][r], pinf);
         }
     }
 #undef XLOADB
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
                         x = acc[m][0][r];
 #pragma unroll
                         for (int jj = 1; jj < 4; ++jj)
-                            if (jj < nmem) x = fmaxf(x, acc[m][jj][r]);
+                            if (jj < nmem) x = vmax_f32(x, acc[m][jj][r], pinf);
                     }
                     x = fmaf(x, gm.x_inv_scale, bv[r]);
                     if (gm.relu) x = fmaxf(x, 0.f);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
                     v = acc[m][0][r];
 #pragma unroll
                     for (int j = 1; j < 4; ++j)
-                        if (j < nmem) v = fmaxf(v, acc[m][j][r]);
+                        if (j < nmem) v = vmax_f32(v, acc[m][j][r], pinf);
                 }
                 v = fmaf(v, gm.x_inv_scale, bias);   // 2^-S > 0 commutes with the maximum
                 if (gm.relu) v = fmaxf(v, 0.f);
