@@ -1,3 +1,4 @@
+# conv_band k-loop ablations (results wrong): build the variants first -- for a in 1 2 3; do tools/variant.sh band_abl$a conv_band.hip "-DBAND_ABLATE=$a"; done
 cd /root/repo
 export TMPDIR=/tmp
 for n in default band_abl1 band_abl2 band_abl3 default; do
