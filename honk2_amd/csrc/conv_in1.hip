@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
     {
         const float* src = p.feat + (size_t)b * p.T * p.F;
         const int gpr = p.F / 4, nitem = p.T * gpr, nel = p.T * p.F;
-        float amax = 0.f;
+        unsigned amax_u = 0u;     // largest |x| as a bit pattern: orders like the magnitudes, and a NaN (which fmaxf would drop) sorts above every number
         for (int i = tid; i < nitem; i += 256) {
             const int row = i / gpr, k = i - row * gpr;
             const int e0 = row * p.F + 4 * k;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
             for (int e = 0; e < 4; ++e) {
                 x[e] = v0[e];
                 x[4 + e] = v1[e];
-                amax = fmaxf(amax, fabsf(v0[e]));
+                amax_u = max(amax_u, __builtin_bit_cast(unsigned, v0[e]) & 0x7fffffffu);
             }
             unsigned h[4], l[4];
             in1_split8(x, h, l);
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
                 *reinterpret_cast<u32x2*>(base + 3 * copyb) = (u32x2){o2, o3};
             }
         }
-        range_note(p.rg, amax);   // the feature maps come from the caller: checked like any stored activation
+        // the feature maps come from the caller: checked like any stored activation (a NaN counts as out of range), so run_cnn launches no range_check_kernel in front of this kernel
+        range_note(p.rg, __builtin_bit_cast(float, amax_u));
         // Kernel rows past kh (zero weights; kh = 15, 21) of the last output rows read up to three rows past the map: the gap behind
         // every copy and the tail behind the last one must hold finite values (0 x NaN would poison the accumulator, and the
         // running maximum silently drops a NaN member)

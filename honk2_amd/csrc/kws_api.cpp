@@ -909,12 +909,13 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
         const int nb = std::min(cb, B - b0);
         auto pass = [&](int terms, RangeGate rg) -> int {
             const float* cur = feat + (size_t)b0 * d.time * d.freq;
-            // the feature maps come from the caller: the first pass checks them like any stored activation
-            if (rg.flag && !rg.gated) HIP_TRY(launch_range_check(cur, (long long)nb * d.time * d.freq, s, rg));
             int m_f16, m_terms;
             decode_mode(terms, m_f16, m_terms);
             size_t first_lin = 0;
             const bool band = cnn_band_plan(h, terms), cl1 = cnn_in1_plan(h, terms);
+            // the feature maps come from the caller: the first pass checks them like any stored activation -- conv_in1_kernel does that while it
+            // stages the clip (NaN-aware); every other conv_0 gets range_check_kernel in front
+            if (rg.flag && !rg.gated && !((band || cl1) && h->cnn_in1)) HIP_TRY(launch_range_check(cur, (long long)nb * d.time * d.freq, s, rg));
             if (band || cl1) {
                 // conv_0 (+ fused MaxPool) writes channels-last cells -- fp32, or fp16 with single-term products: from an LDS image
                 // of the clip (conv_in1.hip) where the layer fits it, else through the generic kernel's channels-last epilogue
