@@ -106,47 +106,116 @@ def cpu_model_string():
     return "unknown"
 
 
+def cgroup_cpu_quota():
+    """CPUs this process may use according to its cgroup (cpu.max, v2; cfs quota, v1), or None when unlimited / unreadable."""
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),):
+        try:
+            with open(path) as f:
+                return parse(f.read())
+        except Exception:
+            pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            q, per = float(f.read()), float(g.read())
+            return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
+CPU_BLOCK = 32      # clips per work item of the CPU port: a block's activations (32 x 727 KB before the pool) stay in a core's cache
+
+
+def cpu_stage_times(torch, x, sd):
+    """CPU microseconds per clip of every stage of the CPU port, ONE thread, blocks of CPU_BLOCK clips as the timed leg runs them:
+    the front end's numpy / scipy steps and the torch-CPU model layer by layer."""
+    import numpy as np
+    import scipy.fft
+    from oracle import frontend, models
+    win = frontend.hann_periodic(frontend.N_FFT, np.float32)
+    bank = frontend.mel_filterbank().T.astype(np.float32)
+    rec = {}
+
+    def lap(name, t0):
+        rec[name] = rec.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
+    for lo in range(0, len(x), CPU_BLOCK):
+        blk = x[lo:lo + CPU_BLOCK]
+        t = time.perf_counter()
+        frames = frontend.frame_signal(blk)
+        t = lap("reflect_pad+framing", t)
+        fw = (frames * win).astype(np.float32)
+        t = lap("hann_window", t)
+        spec = scipy.fft.rfft(fw, axis=-1)
+        t = lap("rfft_480", t)
+        pw = np.abs(spec).astype(np.float32) ** 2
+        t = lap("power", t)
+        mel = np.matmul(pw, bank)
+        t = lap("mel_matmul", t)
+        out = np.array(mel, copy=True)
+        pos = out > 0
+        out[pos] = np.log(out[pos])
+        feats = (2.0 * out).astype(np.float32)
+        t = lap("log_x2", t)
+        models.forward_torch("ResNet", RES8, sd, feats, timer=rec)
+    return {k: round(v / len(x) * 1e6, 2) for k, v in rec.items()}
+
+
 def cpu_baseline(torch, wav_sample, sd, budget_s=12.0):
     """Time the CPU oracle on host cores over a bounded sample (about 10-20 s of CPU work on all granted threads, then ~4 s on
     ONE thread).  Returns the record and the oracle's logits for the clips it evaluated (the parity check compares the GPU's
-    logits with them).  `wav_sample` is ordered so that every prefix of it straddles the whole batch."""
+    logits with them).  `wav_sample` is ordered so that every prefix of it straddles the whole batch.
+    Threads: clips are independent, so the port runs BLOCKS of CPU_BLOCK clips -- front end and model -- on a pool of N worker threads
+    with torch's intra-op pool at one thread (numpy, scipy and torch release the GIL in every heavy step; the reference spreads clips
+    over DataLoader worker processes the same way, data_loader/audio_data_loader.py:10-21).  Round 3's form -- 1 024-clip chunks, numpy's
+    single-threaded steps, torch's intra-op threads on a 745 MB activation tensor -- did not scale (16 threads 1.0 - 1.5 x one thread:
+    conv_0 + ReLU + pool alone was 450 of 680 us per clip and memory-bound); same arithmetic per clip, bit-identical logits.
+    `stages` breaks the per-clip CPU time down (one thread)."""
     import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import frontend, models    # bench-only use of oracle/: the checker and the timed CPU leg, never the product
-    # the one-GPU box exposes every host core but grants a 16-worker share; stay inside the affinity mask and that share
-    threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    torch.set_num_threads(threads)
+    # the one-GPU box exposes every host core but grants a 16-worker share; stay inside the affinity mask, that share and the cgroup's quota
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()
+    threads = max(1, min(16, affinity, int(quota) if quota and quota >= 1 else 16))
+    torch.set_num_threads(1)
     x = wav_sample.cpu().numpy()
 
-    def run(chunk):
-        feats = frontend.compute_mfccs_batch(chunk, "f32")
-        return models.forward_torch("ResNet", RES8, sd, feats)
+    def block(blk):
+        return models.forward_torch("ResNet", RES8, sd, frontend.compute_mfccs_batch(blk, "f32"))
 
-    run(x[:64])                                     # warm-up (thread pools, allocator)
-    t0 = time.perf_counter()
-    run(x[:256])
-    per_clip = (time.perf_counter() - t0) / 256
-    n = int(min(len(x), max(256, budget_s / max(per_clip, 1e-9))))
-    n = max(256, n // 256 * 256)
-    outs = []
-    t0 = time.perf_counter()
-    for lo in range(0, n, 1024):
-        outs.append(run(x[lo:min(lo + 1024, n)]))
-    dt = time.perf_counter() - t0
-    want = np.concatenate([np.asarray(o) for o in outs], 0)[:n]
+    def run(chunk, pool):
+        blocks = [chunk[i:i + CPU_BLOCK] for i in range(0, len(chunk), CPU_BLOCK)]
+        outs = list(pool.map(block, blocks)) if pool is not None else [block(b) for b in blocks]
+        return np.concatenate([np.asarray(o) for o in outs], 0)
+
+    with ThreadPoolExecutor(threads) as pool:
+        run(x[:CPU_BLOCK * threads], pool)          # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        run(x[:CPU_BLOCK * threads * 2], pool)
+        per_clip = (time.perf_counter() - t0) / (CPU_BLOCK * threads * 2)
+        n = int(min(len(x), max(256, budget_s / max(per_clip, 1e-9))))
+        n = max(256, n // 256 * 256)
+        t0 = time.perf_counter()
+        want = run(x[:n], pool)
+        dt = time.perf_counter() - t0
     # the same code on ONE thread (BASELINE.md section 4 asks for both figures): a bounded ~4 s sample
-    torch.set_num_threads(1)
-    run(x[:32])
+    run(x[:CPU_BLOCK], None)
     t1 = time.perf_counter()
     n1 = 0
-    while time.perf_counter() - t1 < 4.0 and n1 + 64 <= len(x):
-        run(x[n1:n1 + 64])
-        n1 += 64
+    while time.perf_counter() - t1 < 4.0 and n1 + CPU_BLOCK <= len(x):
+        run(x[n1:n1 + CPU_BLOCK], None)
+        n1 += CPU_BLOCK
     dt1 = time.perf_counter() - t1
+    stages = {"unit": f"CPU microseconds per clip, one thread, blocks of {CPU_BLOCK} clips", "threads_1": cpu_stage_times(torch, x[:256], sd)}
     torch.set_num_threads(threads)
     rec = {"value": n / dt, "unit": "clips/s", "cores": threads, "kind": "port",
-           "sample": f"{n} of the benchmark's clips (spread over the whole batch), chunks of 1024, numpy/scipy rFFT front end (fp32) + torch-CPU fp32 res8, {dt:.1f} s",
-           "one_thread": {"value": n1 / dt1, "unit": "clips/s", "cores": 1, "sample": f"{n1} clips in chunks of 64, {dt1:.1f} s"},
-           "cpu_model": cpu_model_string(), "host_cores_visible": os.cpu_count(),
+           "sample": f"{n} of the benchmark's clips (spread over the whole batch), blocks of {CPU_BLOCK} clips on {threads} worker threads: numpy/scipy rFFT front end (fp32) + torch-CPU fp32 res8 (one intra-op thread per worker), {dt:.1f} s",
+           "one_thread": {"value": n1 / dt1, "unit": "clips/s", "cores": 1, "sample": f"{n1} clips in blocks of {CPU_BLOCK}, {dt1:.1f} s"},
+           "scaling_1_to_n_threads": (n / dt) / max(n1 / dt1, 1e-9),
+           "stages": stages,
+           "cpu_model": cpu_model_string(), "host_cores_visible": os.cpu_count(), "affinity_cores": affinity, "cgroup_cpu_quota": quota,
+           "loadavg": list(os.getloadavg()) if hasattr(os, "getloadavg") else None,
            "torch_parallel_info": torch.__config__.parallel_info().strip().split("\n")[0:4]}
     return rec, want
 
@@ -277,7 +346,8 @@ def shard_record(torch, model, device, full_rate, full_k_ms, full_f_ms, full_cli
             "efficiency_vs_full_batch": rate / full_rate,
             "res8_kernel_efficiency": (full_k_ms / full_clips) / (k_ms / n) if k_ms > 0 else None,
             "frontend_kernel_efficiency": (full_f_ms / full_clips) / (f_ms / n) if f_ms > 0 else None,
-            "projected_8gpu_speedup": 8.0 * rate / full_rate,
+            "projection_not_a_measurement": {"eight_gpu_speedup_if_every_rank_held_this_shard_rate": 8.0 * rate / full_rate,
+                                             "note": "arithmetic on ONE GPU's shard rate; no multi-GPU run is behind it -- the measured curve is the driver's SCALE record"},
             "what": "wav -> logits on 8 192 clips = one GPU's shard of the 8-GPU run (BASELINE configs[3]); the RCCL all-gather of 393 KB of logits is not in it"}
 
 
@@ -328,6 +398,56 @@ def h2d_record(torch, model, device, nclips, pcm16=False):
             "what": "wav in pinned host memory -> logits on the device, copies of 8 192-clip chunks overlapped with compute (two streams); PCIe-bound, reported beside `value`, never as it"}
 
 
+def literal_tone_record(torch, model, sd, device):
+    """SURVEY.md 8(d)'s tone clip EXACTLY as specified -- 0.5 sin(2 pi 1000 t), no dither; every such clip of the batch is this one
+    clip -- through four front ends: the default three-term fp16 DFT (kws_forward_wav, the benchmark's path), the fp32-input MFMA
+    front end (KWS_FRONTEND_IMPL=fp32), the oracle's complex64-style variant and the oracle in float64; the GPU feature maps go
+    through the GPU model, the oracle's through the oracle's model.  A bin-centred sine leaves every off-peak mel band pure rounding
+    noise (the exact value is ~1e-14 of the peak), so the FEATURES of those bands differ between any two implementations by whole
+    units; what matters for the north-star bar is what that does to the LOGITS, which this record states pair by pair."""
+    import numpy as np
+    from honk2_amd.utils import AudioProcessor
+    from oracle import frontend, models    # bench-only use of oracle/: the checker
+    t = np.arange(16000, dtype=np.float64) / 16000.0
+    tone = (0.5 * np.sin(2.0 * np.pi * 1000.0 * t)).astype(np.float32)[None, :]
+    wav = torch.from_numpy(tone).to(device)
+    feats, logits = {}, {}
+    logits["gpu_f16x3"] = model.forward_wav(wav).cpu().numpy().astype(np.float64)
+    feats["gpu_f16x3"] = AudioProcessor().compute_mfccs_batch(wav).cpu().numpy()
+    old = os.environ.get("KWS_FRONTEND_IMPL")
+    os.environ["KWS_FRONTEND_IMPL"] = "fp32"           # read by kws_create: a fresh front-end handle takes the fp32-input MFMA kernel
+    try:
+        f32k = AudioProcessor().compute_mfccs_batch(wav)
+    finally:
+        if old is None:
+            os.environ.pop("KWS_FRONTEND_IMPL", None)
+        else:
+            os.environ["KWS_FRONTEND_IMPL"] = old
+    feats["gpu_fp32_mfma"] = f32k.cpu().numpy()
+    logits["gpu_fp32_mfma"] = model(f32k).cpu().numpy().astype(np.float64)
+    feats["oracle_f32"] = frontend.compute_mfccs_batch(tone, "f32")
+    logits["oracle_f32"] = np.asarray(models.forward_torch("ResNet", RES8, sd, feats["oracle_f32"])).astype(np.float64)
+    feats["oracle_f64"] = frontend.compute_mfccs_batch(tone, "f64")
+    logits["oracle_f64"] = models.forward_numpy("ResNet", RES8, sd, feats["oracle_f64"], np.float64)
+    mel = frontend.mel_power(tone, "f64")
+    near = mel > 1e-4 * mel.max()                      # bands within 40 dB of the clip's strongest band
+    names = list(logits)
+    pairs = {}
+    for i, a in enumerate(names):
+        for b in names[i + 1:]:
+            df = np.abs(feats[a].astype(np.float64) - feats[b].astype(np.float64))
+            pairs[f"{a} vs {b}"] = {"max_abs_dlogit": float(np.abs(logits[a] - logits[b]).max()),
+                                    "argmax_equal": bool(logits[a].argmax(1)[0] == logits[b].argmax(1)[0]),
+                                    "max_abs_dfeature_within_40dB_of_peak": float(df[near].max()),
+                                    "max_abs_dfeature_all_bands": float(df.max())}
+    top = np.sort(logits["oracle_f64"][0])
+    worst = max(v["max_abs_dlogit"] for v in pairs.values())
+    return {"clip": "0.5 * sin(2 pi 1000 t), 16 000 samples, float32 (SURVEY.md 8d, literal)", "pairs": pairs,
+            "oracle_f64_margin_top1_top2": float(top[-1] - top[-2]), "worst_pair_max_abs_dlogit": worst,
+            "tol": 1e-3, "pass": bool(worst <= 1e-3 and all(v["argmax_equal"] for v in pairs.values())),
+            "bands_within_40dB": int(near.sum()), "bands_total": int(near.size)}
+
+
 def parity_record(got, want, tol=1e-3):
     """GPU logits vs the oracle's on the same clips: the north-star bar (|diff| <= 1e-3, argmax equal).  With |diff| <= e on
     every logit the argmax can only differ where the oracle's own top-1 / top-2 margin is below 2 e, so a mismatch on a
@@ -371,8 +491,11 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
     # KWS_BENCH_BACKEND / KWS_BENCH_ONE_DEVICE are rehearsal knobs only (several ranks on one GPU over gloo, to exercise
     # the N > 1 code path on a single-GPU box); the real multi-GPU run uses RCCL with one GPU per rank.
+    # KWS_FORCE_DIST=1 (under torchrun, one rank): the N > 1 code path -- process group, side-stream all-gather, barrier, all-reduce --
+    # on a one-rank RCCL communicator, so that a one-GPU box executes every RCCL call the multi-GPU run makes.
     backend = os.environ.get("KWS_BENCH_BACKEND", "nccl")
     rank, world = dist_utils.init_from_env(backend)
+    dist_on = dist_utils.active()
     local = 0 if os.environ.get("KWS_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -383,7 +506,7 @@ def main():
     wav = synth_wav(torch, lo, hi, 1234, device)
     logits = torch.empty((nloc, RES8["n_labels"]), dtype=torch.float32, device=device)
     counts = [b - a for a, b in (dist_utils.shard_bounds(args.batch, r, world) for r in range(world))]
-    gathered = torch.empty((args.batch, RES8["n_labels"]), dtype=torch.float32, device=device) if world > 1 else None
+    gathered = torch.empty((args.batch, RES8["n_labels"]), dtype=torch.float32, device=device) if dist_on else None
 
     # N > 1: the all-gather of step i runs on a side stream while step i + 1 computes (two logits / gather buffers in
     # rotation; the compute stream waits for the collective that last read a buffer before overwriting it).  Everything is
@@ -391,7 +514,8 @@ def main():
     # (KWS_BENCH_SELF_GATHER=1, one rank: the same stream / event / buffer rotation with a device copy standing in for the
     # collective -- lets a one-GPU test exercise the ordering logic that the multi-GPU run relies on)
     self_gather = world == 1 and bool(os.environ.get("KWS_BENCH_SELF_GATHER"))
-    overlap = (world > 1 and backend == "nccl" and len(set(counts)) == 1) or self_gather
+    overlap = (dist_on and backend == "nccl" and len(set(counts)) == 1) or self_gather
+    overlap_fallback = None
     if self_gather:
         gathered = torch.zeros_like(logits)
     lbufs = [logits, torch.empty_like(logits)] if overlap else [logits]
@@ -407,7 +531,7 @@ def main():
         except Exception as exc:   # noqa: BLE001
             if rank == 0:
                 print(f"bench: overlapped all-gather unavailable ({exc!r}); gathering on the compute stream", file=sys.stderr)
-            overlap = False
+            overlap, overlap_fallback = False, repr(exc)
             lbufs, gbufs, coll_stream = [logits], [gathered], None
     coll_done = [None, None]
     state = {"i": 0}
@@ -430,7 +554,7 @@ def main():
                     dist.all_gather_into_tensor(gbufs[b], lbufs[b])   # RCCL over xGMI: the path's only collective
                 coll_done[b] = torch.cuda.Event()
                 coll_done[b].record(coll_stream)
-        elif world > 1:
+        elif dist_on:
             if backend != "nccl":                                  # rehearsal over gloo: collectives on host copies
                 gbufs[0].copy_(dist_utils.all_gather_rows(lbufs[0].cpu(), counts))
             else:
@@ -448,14 +572,14 @@ def main():
     torch.cuda.synchronize()
     engine.profile_enable(True)
     engine.profile_read()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -465,7 +589,7 @@ def main():
     logits, gathered = lbufs[last], gbufs[last]
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     if not bool(torch.isfinite(logits).all()):
@@ -521,6 +645,9 @@ def main():
                                    f"(BASELINE configs[3]), {nloc} clips/GPU, random-init weights",
                        "global_batch": args.batch, "clips_per_gpu": nloc, "n_samples": 16000,
                        "plan": model.plan_name(), "parallelism": f"dp{world} (clip sharding, logits all-gather" + (" on a side stream, overlapped with the next step" if overlap else "") + ")"},
+            "collective": ({"backend": dist.get_backend(), "world_size": world, "forced_one_rank_group": dist_utils.forced() and world == 1,
+                            "op": "all_gather_into_tensor of the (B/N, 12) fp32 logits per step", "overlapped_on_side_stream": bool(overlap),
+                            "overlap_fallback": overlap_fallback} if dist_on else None),
             "roofline": roofline,
             "frontend": {"kernel": "frontend_f16_kernel (reflect pad + Hann + 480-point DFT as three-term fp16 MFMA products + mel + log)",
                          "kernel_ms": f_ms, "bound": "hbm", "bytes_per_clip": 80160,
@@ -541,6 +668,11 @@ def main():
             out["parity"] = parity_record(logits[idx[:len(want)]].cpu().numpy(), want)
             out["parity"]["clip_index_range"] = [int(idx[:len(want)].min()), int(idx[:len(want)].max())]
             failed = not out["parity"]["pass"]
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["parity_literal_tone"] = literal_tone_record(torch, model, sd, device)
+            except Exception as exc:                   # never let an extra record take the headline line down
+                out["parity_literal_tone"] = {"error": repr(exc)}
         if world == 1 and not args.no_shard and args.batch >= 16384:
             out["shard"] = shard_record(torch, model, device, clips_per_s, k_ms, f_ms, nloc)
         if world == 1 and not args.no_h2d:
@@ -558,11 +690,11 @@ def main():
         dump = os.environ.get("KWS_BENCH_DUMP")        # tests: the (gathered) logits of the last step, for comparison across N
         if dump:
             import numpy as np
-            np.save(dump, (gathered if (world > 1 or self_gather) else logits).cpu().numpy())
+            np.save(dump, (gathered if (dist_on or self_gather) else logits).cpu().numpy())
         print(json.dumps(out))
         if failed:
             raise SystemExit("parity check failed: " + json.dumps({"headline": out.get("parity"), "secondary": [r.get("parity") for r in out.get("secondary", []) if isinstance(r, dict)]}))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

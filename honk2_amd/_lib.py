@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KWS_LIB") or os.path.join(_HERE, "libkws_hip.so")
 
 KWS_MODEL_NONE, KWS_MODEL_RESNET, KWS_MODEL_CNN = 0, 1, 2
+KWS_OK, KWS_EINVAL, KWS_ENOMEM, KWS_EUNSUPPORTED, KWS_ENOWORKSPACE, KWS_ENOWEIGHTS, KWS_EHIP = 0, -1, -2, -3, -4, -5, -6
 KWS_DTYPE_F32, KWS_DTYPE_BF16X3, KWS_DTYPE_BF16, KWS_DTYPE_F16 = 0, 1, 2, 3
 DTYPES = {"f32": KWS_DTYPE_F32, "fp32": KWS_DTYPE_F32, "float32": KWS_DTYPE_F32, "bf16x3": KWS_DTYPE_BF16X3,
           "bf16": KWS_DTYPE_BF16, "bfloat16": KWS_DTYPE_BF16, "fp16": KWS_DTYPE_F16, "f16": KWS_DTYPE_F16,

@@ -452,7 +452,7 @@ static hipError_t launch_t3k(const TileConvParams& p, hipStream_t s) {
     auto k = conv3x3_tile_kernel<NB, MT, TERMS, F16>;
     static DeviceOnce attr_once;   // per instantiation: allow > 64 KB of dynamic LDS
     if (attr_once.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = allow_big_lds_at_base_zero(reinterpret_cast<const void*>(k));
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
@@ -808,7 +808,7 @@ static hipError_t launch_pair_k(const PairConvParams& p, hipStream_t s) {
     auto k = conv3x3_pair_kernel<6, 3, F16, JTB, WGS>;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = allow_big_lds_at_base_zero(reinterpret_cast<const void*>(k));
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);

@@ -86,6 +86,7 @@ __device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, con
     constexpr bool STEP_AHEAD = TERMS < 3;
     constexpr int NBUF = STEP_AHEAD ? 2 * NTL : 2;
     static_assert((NA * NTL) % 2 == 0, "the two-buffer ring keeps its phase from block to block");
+    static_assert(!STEP_AHEAD || NA % 2 == 0, "single-term products pick the buffer set by (u & 1): an odd BAND_APF + 1 flips it between unrolled blocks");
     u32x4 a[NA][MH][NP], b[NBUF][NP];
     auto load_a = [&](u32x4 (&ar)[MH][NP], int st) {
 #pragma unroll
@@ -390,7 +391,7 @@ static hipError_t launch_band_k(const BandConvParams& p, hipStream_t s) {
     auto k = conv_band_kernel<MH, TERMS, NT>;
     static DeviceOnce attr_once;   // per instantiation: allow > 64 KB of dynamic LDS
     if (attr_once.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = allow_big_lds_at_base_zero(reinterpret_cast<const void*>(k));
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3((unsigned)(p.B * p.nbands)), dim3(256), lds, s, p);

@@ -216,10 +216,11 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
         if (lane == 63) red[w] = v;
     };
 
-    // Units are handed out by a device-wide counter (p.queue starts at gridDim.x; the first unit is blockIdx.x): the two
+    // Units are handed out by a device-wide counter (the first unit is blockIdx.x, ticket t is unit gridDim.x + t): the two
     // workgroups of a CU do not progress at the same rate (res8_f16x3.hip), a fixed stride leaves the favoured one idle
     // at the end.  The counter is read at the top of an iteration and published through one LDS word well before the
-    // prefetch of the next unit needs it.
+    // prefetch of the next unit needs it.  The counter RESETS ITSELF (kws_internal.h, queue_retire): no memset in front
+    // of the launch, so the launch is one graph node whose state does not depend on another node's.
     int unit = blockIdx.x;
     if (unit < nunits) {
         issue(unit, tid0);
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
 #pragma unroll 1
     while (unit < nunits) {
     int taken = 0;
-    if (tid0 == 0) taken = (int)atomicAdd(p.queue, 1u);
+    if (tid0 == 0) taken = (int)(gridDim.x + atomicAdd(p.queue, 1u));
     int tid = tid0;
     asm volatile("" : "+v"(tid));      // lane-derived values are recomputed per unit instead of living across the loop
     const int lane = tid & 63;
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
 #endif
     unit = nxt;
     }
+    if (tid0 == 0) queue_retire(p.queue);
 }
 
 int frontend_f16_frames() { return FRM; }
@@ -610,8 +612,6 @@ hipError_t launch_frontend_f16(const FrontendParams& p, int n_cu, hipStream_t s)
     static const int wgs_env = std::getenv("KWS_FE_WGS_PER_CU") ? std::atoi(std::getenv("KWS_FE_WGS_PER_CU")) : 0;   // experiments
     const int wgs = wgs_env > 0 && wgs_env < WG_PER_CU ? wgs_env : WG_PER_CU;
     const dim3 grid((unsigned)std::min<long long>(units, (long long)wgs * n_cu));      // persistent
-    hipError_t qe = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.queue), (int)grid.x, 1, s);   // units 0 .. grid-1 go by blockIdx
-    if (qe != hipSuccess) return qe;
     if (p.wav) hipLaunchKernelGGL(frontend_f16_kernel<0>, grid, dim3(256), lds, s, p);
     else if (!p.noise) hipLaunchKernelGGL(frontend_f16_kernel<1>, grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL(frontend_f16_kernel<2>, grid, dim3(256), lds, s, p);

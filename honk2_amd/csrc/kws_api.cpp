@@ -7,8 +7,11 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <new>
 #include <set>
+#include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "kws_internal.h"
@@ -46,6 +49,15 @@ struct DevMem {
             bytes = n;
         }
         HIP_TRY(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+        return KWS_OK;
+    }
+    int reserve(size_t n) {   // grow only; contents are not kept (hipFree waits for the device: nothing in flight still reads the old block)
+        if (bytes >= n) return KWS_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        HIP_TRY(hipMalloc(&p, n));
+        bytes = n;
         return KWS_OK;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -135,6 +147,7 @@ struct kws_handle {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     bool t3_pair = true;                   // tiled plan, 16-bit tensors: consecutive layers of equal dilation in one kernel (KWS_T3_PAIR=0: off)
+    DevMem r8_shift;                       // fused res8, kws_forward: per-clip power-of-two shifts of caller-provided features (feat_shift_kernel)
     DevMem range_flag;                     // device words: [0] fp16 range guard of the layer-wise plans (kws_internal.h), [16] /
                                            // [32] clip / unit counters of the fused res8 and front-end kernels
 
@@ -269,6 +282,9 @@ int resnet_dilation(const kws_model_desc& d, int i) { return d.use_dilation ? 1 
 int build_resnet(kws_handle* h) {
     const kws_model_desc& d = h->d;
     if (d.n_layers < 1 || d.n_feature_maps < 1 || d.n_labels < 1) return fail(KWS_EINVAL, "bad ResNet description");
+    // sizes are bounded BEFORE anything is allocated from them (a depth of INT_MAX must come back as a code, not as a terabyte resize)
+    if (d.n_layers > 1024 || d.n_feature_maps > 4096 || d.n_labels > 65536 || d.freq < 1 || d.freq > 65536)
+        return fail(KWS_EUNSUPPORTED, "ResNet description out of range (n_layers <= 1024, n_feature_maps <= 4096, n_labels <= 65536, freq <= 65536)");
     const int C = d.n_feature_maps;
     h->rconv.resize(d.n_layers + 1);
     h->rconv[0].g = make_geom(1, C, 3, 3, 1, 1, 1, 1, 1, 1, 1);
@@ -301,6 +317,13 @@ int build_resnet(kws_handle* h) {
 int build_cnn(kws_handle* h) {
     const kws_model_desc& d = h->d;
     if (d.n_conv < 1 || d.n_conv > 2 || d.time < 1 || d.freq < 1) return fail(KWS_EINVAL, "bad CNN description");
+    if (d.time > (1 << 20) || d.freq > 65536 || d.n_labels < 1 || d.n_labels > 65536 || d.lin0_out < 0 || d.lin0_out > (1 << 20) ||
+        d.dnn0_out < 0 || d.dnn0_out > (1 << 20) || d.dnn1_out < 0 || d.dnn1_out > (1 << 20))
+        return fail(KWS_EUNSUPPORTED, "CNN description out of range (time <= 2^20, freq <= 65536, n_labels <= 65536, linear widths <= 2^20)");
+    for (int i = 0; i < d.n_conv; ++i)
+        if (d.conv[i].out_channels > 4096 || d.conv[i].kernel_h > 4096 || d.conv[i].kernel_w > 4096 || d.conv[i].stride_h > 4096 ||
+            d.conv[i].stride_w > 4096 || d.pool_kh[i] > 4096 || d.pool_kw[i] > 4096)
+            return fail(KWS_EUNSUPPORTED, "conv/pool description out of range (channels, kernel, stride, pool <= 4096)");
     int C = 1, H = d.time, W = d.freq;
     h->cnn_shape[0][0] = C; h->cnn_shape[0][1] = H; h->cnn_shape[0][2] = W;
     h->cconv.resize(d.n_conv);
@@ -638,7 +661,7 @@ size_t cnn_partial_bytes(const kws_handle* h, int cb) {
 
 size_t act_bytes(const kws_handle* h, int B, int T) {
     if (h->plan == PLAN_RESNET) {
-        if (use_fused(h, T)) return h->res8_impl == 0 ? align256((size_t)B * sizeof(int)) : 0;   // per-clip feature shifts (kws_forward)
+        if (use_fused(h, T)) return 0;   // (kws_forward's per-clip feature shifts live in a buffer of the handle: r8_shift)
         const ResnetShape s = resnet_shape(h, T);
         const size_t full = (size_t)s.C * s.T * s.F, small = (size_t)s.C * s.H * s.W;
         if (resnet_tiled(h, s)) {   // three channels-last tensors (conv_0 writes the first one directly)
@@ -1049,7 +1072,10 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 p.terms = h->d.dtype == KWS_DTYPE_F16 ? 1 : 3;
                 p.queue = h->range_flag.as<unsigned>() + 16;   // (word 0 of that block is the layer-wise range flag)
                 if (!own_feat) {   // caller-provided features: any finite fp32 value (reference model/resnet.py:39-41)
-                    int* fsh = reinterpret_cast<int*>(ws_act);
+                    // B words of the handle's own (ABI version 2 promised that kws_forward needs no workspace on this plan): grown, with a
+                    // blocking allocation, the first time a larger batch arrives -- one more reason for the un-captured warm-up call
+                    if ((rc = h->r8_shift.reserve(align256((size_t)B * sizeof(int))))) return rc;
+                    int* fsh = h->r8_shift.as<int>();
                     HIP_TRY(launch_feat_shift(feat, B, T * h->d.freq, fsh, s));
                     p.feat_shift = fsh;
                 }
@@ -1099,6 +1125,32 @@ int strip_and_match(const char* name, std::string& out) {
 
 }  // namespace
 
+// Nothing may throw across the C ABI (include/kws.h): every entry point runs inside this guard.  std::bad_alloc (std::vector /
+// std::string growth in kws_create, kws_load_weights and finalize) becomes KWS_ENOMEM, anything else KWS_EINVAL with the
+// exception's message; size queries return 0.
+template <typename R, typename F>
+static R guarded(F&& body) noexcept {
+    int code = KWS_EINVAL;
+    const char* what = "unexpected C++ exception";
+    char msg[256];
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        code = KWS_ENOMEM;
+        what = "out of host memory";
+    } catch (const std::exception& e) {
+        std::snprintf(msg, sizeof(msg), "%s", e.what());
+        what = msg;
+    } catch (...) {
+    }
+    try {
+        g_err = what;
+    } catch (...) {
+        g_err.clear();
+    }
+    return std::is_same<R, size_t>::value ? (R)0 : (R)code;
+}
+
 // ================================================================================================== C ABI
 extern "C" {
 
@@ -1106,7 +1158,12 @@ int kws_abi_version(void) { return KWS_ABI_VERSION; }
 const char* kws_last_error(void) { return g_err.c_str(); }
 
 int kws_create(const kws_model_desc* desc, kws_handle** out) {
+    return guarded<int>([&]() -> int {
     if (!desc || !out) return fail(KWS_EINVAL, "null argument");
+    if (const char* t = std::getenv("KWS_TEST_THROW")) {   // fault injection for tests/test_host.py: what the guard makes of an exception
+        if (std::strcmp(t, "bad_alloc") == 0) throw std::bad_alloc();
+        throw std::runtime_error(t);
+    }
     if (desc->struct_size != (int)sizeof(kws_model_desc)) return fail(KWS_EINVAL, "kws_model_desc size mismatch (ABI)");
     if (desc->dtype != KWS_DTYPE_F32 && desc->dtype != KWS_DTYPE_BF16X3 && desc->dtype != KWS_DTYPE_BF16 &&
         desc->dtype != KWS_DTYPE_F16)
@@ -1141,11 +1198,18 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
     if (rc) return rc;
     *out = h.release();
     return KWS_OK;
+    });
 }
 
-void kws_destroy(kws_handle* h) { delete h; }
+void kws_destroy(kws_handle* h) {
+    try {
+        delete h;
+    } catch (...) {
+    }
+}
 
 int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, size_t bytes) {
+    return guarded<int>([&]() -> int {
     DeviceGuard dg(h);
     if (!h || !host_ptr) return fail(KWS_EINVAL, "null argument");
     std::string name;
@@ -1248,19 +1312,25 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
     h->loaded.insert(name);
     h->dirty = true;
     return KWS_OK;
+    });
 }
 
 int kws_num_frames(const kws_handle* h, int n_samples) {
+    return guarded<int>([&]() -> int {
     if (!h || n_samples < 0) return fail(KWS_EINVAL, "bad argument");
     return 1 + n_samples / h->d.hop_length;
+    });
 }
 
 size_t kws_workspace_bytes(const kws_handle* h, int B, int T) {
+    return guarded<size_t>([&]() -> size_t {
     if (!h || B < 0 || T < 1) return 0;
     return feat_bytes(h, B, T) + act_bytes(h, B, T);
+    });
 }
 
 int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes) {
+    return guarded<int>([&]() -> int {
     DeviceGuard dg(h);
     if (!h) return fail(KWS_EINVAL, "null handle");
     if (d_ptr && (reinterpret_cast<uintptr_t>(d_ptr) & 255)) return fail(KWS_EINVAL, "workspace must be 256-byte aligned");
@@ -1273,6 +1343,7 @@ int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes) {
         HIP_TRY(hipStreamSynchronize(nullptr));
     }
     return KWS_OK;
+    });
 }
 
 static int mfcc_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, const float* d_noise, float noise_pct,
@@ -1305,15 +1376,20 @@ static int mfcc_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, con
 }
 
 int kws_mfcc(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_feat, void* stream) {
+    return guarded<int>([&]() -> int {
     return mfcc_any(h, d_wav, nullptr, nullptr, 0.f, B, n_samples, d_feat, stream);
+    });
 }
 
 int kws_mfcc_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise, float noise_pct, int B, int n_samples,
                    float* d_feat, void* stream) {
+    return guarded<int>([&]() -> int {
     return mfcc_any(h, nullptr, d_pcm, d_noise, noise_pct, B, n_samples, d_feat, stream);
+    });
 }
 
 int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits, void* stream) {
+    return guarded<int>([&]() -> int {
     DeviceGuard dg(h);
     if (!h || !d_feat || !d_logits || B < 0 || T < 1) return fail(KWS_EINVAL, "bad argument");
     int rc = finalize(h);
@@ -1325,6 +1401,7 @@ int kws_forward(kws_handle* h, const void* d_feat, int B, int T, void* d_logits,
     if (ws_act) ws_act = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(ws_act) & ~(uintptr_t)255);
     return run_model(h, static_cast<const float*>(d_feat), B, T, static_cast<float*>(d_logits), ws_act,
                      static_cast<hipStream_t>(stream), false);
+    });
 }
 
 static int forward_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, const float* d_noise, float noise_pct,
@@ -1343,12 +1420,16 @@ static int forward_any(kws_handle* h, const float* d_wav, const int16_t* d_pcm, 
 }
 
 int kws_forward_wav(kws_handle* h, const float* d_wav, int B, int n_samples, float* d_logits, void* stream) {
+    return guarded<int>([&]() -> int {
     return forward_any(h, d_wav, nullptr, nullptr, 0.f, B, n_samples, d_logits, stream);
+    });
 }
 
 int kws_forward_pcm16(kws_handle* h, const int16_t* d_pcm, const float* d_noise, float noise_pct, int B, int n_samples,
                       float* d_logits, void* stream) {
+    return guarded<int>([&]() -> int {
     return forward_any(h, nullptr, d_pcm, d_noise, noise_pct, B, n_samples, d_logits, stream);
+    });
 }
 
 static int check_windows(size_t n_stream, int window, int shift, int n_windows) {
@@ -1389,13 +1470,16 @@ static int mfcc_windows_impl(kws_handle* h, const float* d_stream, int window, i
 }
 
 size_t kws_workspace_bytes_windows(const kws_handle* h, int window, int shift, int n_windows) {
+    return guarded<size_t>([&]() -> size_t {
     if (!h || window < 1 || shift < 1 || n_windows < 0) return 0;
     const size_t base = kws_workspace_bytes(h, n_windows, 1 + window / FE_HOP);
     return base + (windows_share_frames(window, shift, n_windows) ? global_feat_bytes(h, window, shift, n_windows) : 0);
+    });
 }
 
 int kws_mfcc_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
                      float* d_feat, void* stream) {
+    return guarded<int>([&]() -> int {
     DeviceGuard dg(h);
     if (!h) return fail(KWS_EINVAL, "null handle");
     int rc = check_windows(n_stream, window, shift, n_windows);
@@ -1403,10 +1487,12 @@ int kws_mfcc_windows(kws_handle* h, const float* d_stream, size_t n_stream, int 
     // the scratch for the stream's own frames comes from the head of the workspace when there is one that is big enough
     float* gbuf = (h->ws && h->ws_bytes >= global_feat_bytes(h, window, shift, n_windows)) ? static_cast<float*>(h->ws) : nullptr;
     return mfcc_windows_impl(h, d_stream, window, shift, n_windows, d_feat, stream, gbuf);
+    });
 }
 
 int kws_forward_windows(kws_handle* h, const float* d_stream, size_t n_stream, int window, int shift, int n_windows,
                         float* d_logits, void* stream) {
+    return guarded<int>([&]() -> int {
     DeviceGuard dg(h);
     if (!h || !d_stream || !d_logits) return fail(KWS_EINVAL, "bad argument");
     int rc = check_windows(n_stream, window, shift, n_windows);
@@ -1421,19 +1507,23 @@ int kws_forward_windows(kws_handle* h, const float* d_stream, size_t n_stream, i
     if ((rc = mfcc_windows_impl(h, d_stream, window, shift, n_windows, feat, stream, gbuf))) return rc;
     char* ws_act = ab ? static_cast<char*>(h->ws) + fb : nullptr;
     return run_model(h, feat, n_windows, T, d_logits, ws_act, static_cast<hipStream_t>(stream), true);
+    });
 }
 
 int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target, int B, int64_t* d_stats,
                    double* d_loss_sum, void* stream) {
+    return guarded<int>([&]() -> int {
     DeviceGuard dg(h);
     if (!h || !d_logits || !d_target || !d_stats || !d_loss_sum || B < 0) return fail(KWS_EINVAL, "bad argument");
     HIP_TRY(launch_eval_tail(d_logits, d_target, B, h->d.n_labels, d_stats, d_loss_sum, static_cast<hipStream_t>(stream)));
     return KWS_OK;
+    });
 }
 
 const char* kws_plan_name(const kws_handle* h) { return h ? h->last_plan : "none"; }
 
 int kws_profile_enable(kws_handle* h, int enable) {
+    return guarded<int>([&]() -> int {
     DeviceGuard dg(h);
     if (!h) return fail(KWS_EINVAL, "null handle");
     h->prof = enable != 0;
@@ -1443,9 +1533,11 @@ int kws_profile_enable(kws_handle* h, int enable) {
         h->ev_pool.push_back(e);
     }
     return KWS_OK;
+    });
 }
 
 int kws_profile_read(kws_handle* h, double* model_ms, double* frontend_ms, int* calls) {
+    return guarded<int>([&]() -> int {
     DeviceGuard dg(h);
     if (!h) return fail(KWS_EINVAL, "null handle");
     auto drain = [&](std::vector<hipEvent_t>& v, double& acc) -> int {
@@ -1468,6 +1560,7 @@ int kws_profile_read(kws_handle* h, double* model_ms, double* frontend_ms, int* 
     h->ev_next = 0;
     h->acc_model_ms = h->acc_front_ms = 0;
     return KWS_OK;
+    });
 }
 
 }  // extern "C"

@@ -71,6 +71,18 @@ struct DeviceOnce {
     }
 };
 
+// Kernels that address LDS through absolute 32-bit integers (conv3x3_tile.hip, conv_band.hip) assume their dynamic LDS starts at LDS
+// address 0, i.e. that the kernel holds NO static __shared__.  Checked on the host, once per instantiation and device, where the dynamic
+// LDS limit is raised: a static array added to such a translation unit fails the first launch with an error code instead of aborting on
+// the GPU (the kernels keep a __builtin_trap() behind the same condition as a last line of defence).
+inline hipError_t allow_big_lds_at_base_zero(const void* kernel, int bytes = 160 * 1024) {
+    hipFuncAttributes fa{};
+    hipError_t e = hipFuncGetAttributes(&fa, kernel);
+    if (e != hipSuccess) return e;
+    if (fa.sharedSizeBytes != 0) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -99,6 +111,17 @@ __device__ __forceinline__ float opaque_pinf() {
 __device__ __forceinline__ float vmax_f32(float a, float b, float pinf) { return __builtin_amdgcn_fmed3f(a, b, pinf); }
 __device__ __forceinline__ bool range_gate_closed(const RangeGate& rg) {
     return rg.gated && rg.flag && __builtin_nontemporal_load(rg.flag) == 0u;
+}
+// Work queue of a persistent kernel: q[0] = tickets drawn so far, q[1] = workgroups that have retired, both zero between
+// launches.  A workgroup starts on unit blockIdx.x, then draws tickets (unit = gridDim.x + atomicAdd(q, 1)) until it draws one
+// past the end; ONE thread of it then calls queue_retire.  Every workgroup's last draw has returned before it retires, so the
+// workgroup that retires last knows no draw is outstanding and puts both words back to zero: the launch leaves the queue as
+// it found it, and needs no memset in front of it (a memset is a separate graph node; this is why there is none).
+__device__ __forceinline__ void queue_retire(unsigned* q) {
+    if (atomicAdd(q + 1, 1u) == gridDim.x - 1) {
+        atomicExch(q, 0u);
+        atomicExch(q + 1, 0u);
+    }
 }
 __device__ __forceinline__ void range_note(const RangeGate& rg, float amax) {
     if (!rg.gated && rg.flag && !(amax < KWS_RANGE_LIMIT)) *rg.flag = 1u;   // (a NaN flags too) same value from every writer: a benign race
@@ -137,7 +160,7 @@ struct FrontendParams {
     // over m = 0, 1, 2: [step][lane] = W[16 m + (lane & 15)][4 (fb + s) + (lane >> 4)]
     const float* mel_a;
     int mel_fb[3], mel_ns[3];
-    unsigned* queue;         // device word: next unit to hand out (frontend_f16_kernel; its launcher sets it to the grid size)
+    unsigned* queue;         // two device words, zero between launches: frontend_f16_kernel's unit queue (queue_retire above)
 };
 constexpr int FE16_MAX_MELS = 48, FE16_MAX_STEPS = 64;   // what frontend_f16_kernel's mel stage holds: three band tiles, 64 k-steps
 constexpr int FE16_CONST_WORDS = 256;
@@ -230,7 +253,7 @@ struct Res8hParams {
     int B, T, F, n_labels;
     int debug;            // timing experiments only: 1 skip conv_0, 2 skip the MFMA loop
     int terms;            // 3: fp32-accurate products; 1: plain fp16 operands (KWS_DTYPE_F16)
-    unsigned* queue;      // device word: next clip to hand out (launch_res8h sets it to the grid size)
+    unsigned* queue;      // two device words, zero between launches: the clip queue (queue_retire)
     const int* feat_shift;   // per clip: power of two its features are staged down by (launch_feat_shift), or nullptr = 0
 };
 size_t res8h_lds_bytes();

@@ -577,7 +577,8 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
     // Clips are handed out by a device-wide counter, not by a fixed stride: the two workgroups of a CU do NOT progress at
     // the same rate (the SIMDs' arbiters favour the older waves: measured 84 against 106 us per clip, so with a static
     // split the favoured workgroup of every CU sat idle for the last fifth of the launch), and the XCDs differ by a few
-    // per cent as well.  The first clip is blockIdx.x; p.queue starts at gridDim.x.  The counter is read one clip ahead
+    // per cent as well.  The first clip is blockIdx.x, ticket t is clip gridDim.x + t; the counter resets itself when the last
+    // workgroup retires (kws_internal.h, queue_retire: no memset node in front of the launch).  It is read one clip ahead
     // (the atomic is in flight behind the feature loads) and published to the other waves through one LDS word.
     int* const next_clip = reinterpret_cast<int*>(ldsb + NEXT_OFF);
     if (R8H_EPRIO) __builtin_amdgcn_s_setprio(R8H_EPRIO);
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         R8H_TS_DECL
         R8H_TS(0)
         int taken = 0;
-        if (threadIdx.x == 0) taken = (int)atomicAdd(p.queue, 1u);
+        if (threadIdx.x == 0) taken = (int)(gridDim.x + atomicAdd(p.queue, 1u));
 
         // Everything derived from the lane id is recomputed per clip from an opaque copy of it.  Otherwise the compiler
         // hoists some 80 per-lane addresses and selectors out of this loop, keeps them alive across it and -- at 256
@@ -880,6 +881,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
 #endif
         clip = *next_clip;   // written before the staging barrier of this clip; every wave reads it before the loop's top barrier
     }
+    if (threadIdx.x == 0) queue_retire(p.queue);
 }
 
 // per clip: the power of two that brings max |feature| under 2^14 (0 for anything a front end produces); one wave per clip
@@ -912,8 +914,6 @@ hipError_t launch_res8h(const Res8hParams& p, int grid, hipStream_t s) {
         if (e != hipSuccess) return e;
     }
     if (p.B <= 0) return hipSuccess;
-    hipError_t qe = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.queue), grid, 1, s);   // clips 0 .. grid-1 are taken by blockIdx
-    if (qe != hipSuccess) return qe;
     if (p.terms == 1)
         hipLaunchKernelGGL(res8h_kernel<1>, dim3((unsigned)grid), dim3(256), res8h_lds_bytes(), s, p);
     else

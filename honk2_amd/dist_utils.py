@@ -23,10 +23,21 @@ def world():
     return 0, 1
 
 
+def forced():
+    """KWS_FORCE_DIST=1 under torchrun: take the distributed code path (process group, collectives, reductions) even at
+    WORLD_SIZE 1 -- how a one-GPU box executes the RCCL calls the multi-GPU run makes (tests/test_gpu_parity.py)."""
+    return bool(os.environ.get("KWS_FORCE_DIST")) and "MASTER_ADDR" in os.environ
+
+
+def active():
+    """True when results have to be combined over a process group (more than one rank, or a forced one-rank group)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     n = int(os.environ.get("WORLD_SIZE", "1"))
-    if n <= 1 or dist.is_initialized():
+    if dist.is_initialized() or (n <= 1 and not forced()):
         return world()
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"

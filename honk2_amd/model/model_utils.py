@@ -12,6 +12,7 @@ same weights as the reference.
 import ctypes as C
 import math
 import threading
+import weakref
 from abc import ABC
 
 import torch
@@ -61,18 +62,25 @@ class BaseModel(ABC, nn.Module):
         # own device and never touches (let alone destroys) another replica's handle.
         self._engines = {}
         self._engines_lock = threading.Lock()
+        # torch.nn.parallel.replicate() builds a replica as a shallow copy of __dict__ with an EMPTY _parameters dict (the broadcast
+        # copies hang on it as plain attributes and in _former_parameters): a replica has no parameters() and its state_dict() lacks
+        # every weight.  This entry is copied with the rest of __dict__, so a replica can find the module it was made from, whose
+        # tensors are what every device's engine is loaded from (engine()).
+        object.__setattr__(self, "_origin", weakref.ref(self))
 
     # engines are per-process device state: a deep copy / pickle of the module carries the tensors only and builds its own
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_engines", None)
         state.pop("_engines_lock", None)
+        state.pop("_origin", None)
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
         self._engines = {}
         self._engines_lock = threading.Lock()
+        object.__setattr__(self, "_origin", weakref.ref(self))
 
     def num_params(self):
         return sum(p.numel() for p in self.parameters())
@@ -84,15 +92,32 @@ class BaseModel(ABC, nn.Module):
     def _make_desc(self):
         raise NotImplementedError
 
-    def _weights_key(self):
-        return tuple((k, v.data_ptr(), v._version) for k, v in self.state_dict(keep_vars=True).items())
+    def _source(self):
+        """The module whose tensors define the weights: this one, or -- for a DataParallel replica -- the module it was replicated
+        from (a replica's own tensors are per-forward broadcast copies that may reuse an address at version 0)."""
+        src = self._origin() if getattr(self, "_is_replica", False) else self
+        return self if src is None else src
 
-    def engine(self):
-        """The kws_handle of the device this module's tensors live on, with the current weights loaded (re-uploaded when
-        they change).  Engines of other devices stay alive until the module is garbage-collected."""
-        device = next(self.parameters()).device           # (parameters still on the host: the current GPU computes)
+    def _weights_key(self):
+        return tuple((k, v.data_ptr(), v._version) for k, v in self._source().state_dict(keep_vars=True).items())
+
+    def _own_device(self):
+        """Device of this module's own tensors, replicas included (their parameters sit in _former_parameters); None if it has none."""
+        for m in self.modules():
+            for holder in (getattr(m, "_former_parameters", None), m._parameters, m._buffers):
+                for t in (holder or {}).values():
+                    if t is not None:
+                        return t.device
+        return None
+
+    def engine(self, device=None):
+        """The kws_handle of the device this module's tensors live on (or of `device`: the input's, in forward), with the current
+        weights loaded (re-uploaded when they change).  Engines of other devices stay alive until the module is garbage-collected."""
+        if device is None:
+            device = self._own_device()                   # (tensors still on the host: the current GPU computes)
         if not torch.cuda.is_available():
             raise RuntimeError("honk2_amd: no ROCm device visible to PyTorch; the HIP path is mandatory (no CPU fallback)")
+        device = torch.device("cpu") if device is None else torch.device(device)
         index = device.index if device.type == "cuda" and device.index is not None else torch.cuda.current_device()
         key = self._weights_key()
         with self._engines_lock:
@@ -100,7 +125,7 @@ class BaseModel(ABC, nn.Module):
             if slot is None:
                 slot = self._engines[index] = [_lib.Engine(self._make_desc(), torch.device("cuda", index)), None]
             if slot[1] != key:
-                for name, tensor in self.state_dict().items():
+                for name, tensor in self._source().state_dict().items():
                     slot[0].load_tensor(name, tensor)
                 slot[1] = key
             return slot[0]

@@ -95,7 +95,8 @@ def main(config):
     rank, world = dist_utils.init_from_env()
     set_seed(config["seed"])
     device, _ = prepare_device(max(config["num_gpu"], 1))
-    if device.type == "cuda" and world > 1:
+    sharded = dist_utils.active()                      # world > 1, or a forced one-rank process group (dist_utils.forced)
+    if device.type == "cuda" and sharded:
         device = torch.device("cuda", torch.cuda.current_device())
     model = build_model(config).to(device)
     if rank == 0:
@@ -103,7 +104,7 @@ def main(config):
 
     test_data_loader = init_data_loader(config, DatasetType.TEST)
     label_mapping = test_data_loader.dataset.label_mapping
-    if world > 1:
+    if sharded:
         test_data_loader = shard_loader(test_data_loader, rank, world)
     if rank == 0:
         print(f"test dataset size: {len(test_data_loader.dataset)}" + (f" (per rank, {world} ranks)" if world > 1 else ""))
@@ -124,7 +125,7 @@ def main(config):
     elif rank == 0:
         print("no evaluate_model_dir in config: evaluating randomly initialised weights")
 
-    if world > 1:
+    if sharded:
         loss_sum, n_batches = evaluate_partial(device, "test", model, test_data_loader, loss_fn, metrics, progress=rank == 0)
         results = reduce_results(loss_sum, n_batches, metrics, label_mapping, device)
     else:

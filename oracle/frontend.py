@@ -108,12 +108,22 @@ def dct_len1(x):
     return 2.0 * x
 
 
-def compute_mfccs_batch(y, precision="f64", **kw):
+def compute_mfccs_batch(y, precision="f64", workers=1, **kw):
     """(B, n) waveforms -> (B, T, n_mels) float32 features, [b,t,f] = 2*ln(mel[f,t]) where mel>0 else 0.
 
     This is the tensor the reference's collate_fn hands to the model
     (data_loader/audio_data_loader.py:28, reshape(1,-1,40) of the (T,40,1) array).
+    `workers` > 1: blocks of clips on a thread pool (numpy / scipy release the GIL in every heavy step); a clip's arithmetic
+    does not depend on its block, so the result is the same array (bench.py's timed CPU leg uses it; the reference itself
+    spreads clips over DataLoader worker processes, data_loader/audio_data_loader.py:10-21).
     """
+    y = np.atleast_2d(y)
+    if workers > 1 and len(y) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        step = max(16, -(-len(y) // (4 * workers)))
+        blocks = [y[i:i + step] for i in range(0, len(y), step)]
+        with ThreadPoolExecutor(workers) as pool:
+            return np.concatenate(list(pool.map(lambda blk: compute_mfccs_batch(blk, precision, 1, **kw), blocks)), 0)
     m = mel_power(y, precision, **kw)
     out = np.array(m, copy=True)
     pos = out > 0

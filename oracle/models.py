@@ -109,17 +109,28 @@ def _t(sd, key):
     return v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
 
 
-def forward_torch(model_name, cfg, sd, feats):
-    """fp32 on the CPU with torch.nn.functional; feats: (B,T,F) tensor/ndarray -> (B,n_labels) tensor."""
+def forward_torch(model_name, cfg, sd, feats, timer=None):
+    """fp32 on the CPU with torch.nn.functional; feats: (B,T,F) tensor/ndarray -> (B,n_labels) tensor.
+    `timer` (ResNet): a dict that receives the seconds spent per stage (bench.py's cpu_baseline breaks its time down with it)."""
+    import time
     import torch
     import torch.nn.functional as F
     x = feats if isinstance(feats, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(feats))
     x = x.float().unsqueeze(1)
+    t_last = [time.perf_counter()]
+
+    def lap(stage):
+        if timer is not None:
+            now = time.perf_counter()
+            timer[stage] = timer.get(stage, 0.0) + now - t_last[0]
+            t_last[0] = now
+
     with torch.no_grad():
         if model_name == "ResNet":
             x = F.relu(F.conv2d(x, _t(sd, "layers.conv_0.weight"), padding=1))
             if "pool" in cfg:
                 x = F.avg_pool2d(x, tuple(cfg["pool"]))
+            lap("conv_0+relu+pool")
             prev = x
             for i in range(1, cfg["n_layers"] + 1):
                 d = int(2 ** ((i - 1) // 3)) if cfg["use_dilation"] else 1
@@ -129,8 +140,11 @@ def forward_torch(model_name, cfg, sd, feats):
                     prev = x
                 x = F.batch_norm(x, _t(sd, f"layers.bn_{i}.running_mean"), _t(sd, f"layers.bn_{i}.running_var"),
                                  training=False, eps=BN_EPS)
+                lap(f"conv_{i}+relu+bn")
             x = x.reshape(x.size(0), x.size(1), -1).mean(2)
-            return F.linear(x, _t(sd, "layers.output.weight"), _t(sd, "layers.output.bias"))
+            y = F.linear(x, _t(sd, "layers.output.weight"), _t(sd, "layers.output.bias"))
+            lap("mean+linear")
+            return y
         if model_name == "CNN":
             for i in (0, 1):
                 key = f"conv_{i}"

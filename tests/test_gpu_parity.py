@@ -730,6 +730,99 @@ def test_forward_wav_is_graph_capturable_after_one_warm_up_call(torch_cuda, fnam
         assert torch.equal(out, want), float((out - want).abs().max())
 
 
+def test_literal_tone_clip_logits_across_four_front_ends(torch_cuda):
+    """SURVEY.md 8(d)'s tone clip exactly as specified (0.5 sin(2 pi 1000 t), no dither).  A bin-centred sine leaves 90 % of the mel bands
+    pure rounding noise, so the features of those bands -- and through them the logits -- differ between ANY two implementations, the
+    oracle's own complex64-style and float64 variants included (bench.py records the numbers: `parity_literal_tone`).  What has to hold:
+    every pair agrees on the bands that carry signal and on the argmax, and the default three-term fp16 front end is not the outlier --
+    its logits are no further from the complex64-style restatement than the float64 restatement's are."""
+    torch = torch_cuda
+    import bench
+    model, sd = bench.build_model(torch, torch.device("cuda", 0))
+    rec = bench.literal_tone_record(torch, model, sd, torch.device("cuda", 0))
+    pairs = rec["pairs"]
+    assert len(pairs) == 6 and rec["bands_within_40dB"] < 0.2 * rec["bands_total"]
+    for name, p in pairs.items():
+        assert p["argmax_equal"], name
+        assert p["max_abs_dfeature_within_40dB_of_peak"] < 1e-4, (name, p)
+    ref = pairs["oracle_f32 vs oracle_f64"]["max_abs_dlogit"]
+    assert ref > 1e-3                                                     # the clip is ill-conditioned for everybody
+    assert pairs["gpu_f16x3 vs oracle_f32"]["max_abs_dlogit"] <= ref
+    assert pairs["gpu_f16x3 vs oracle_f32"]["max_abs_dlogit"] <= 2.0 * pairs["gpu_fp32_mfma vs oracle_f32"]["max_abs_dlogit"] + 1e-3
+
+
+def test_real_data_parallel_replicas_compute(torch_cuda):
+    """torch.nn.parallel.replicate() itself (the reference's multi-GPU mechanism is nn.DataParallel, run/test.py:69-70), twice onto
+    the one GPU this box has: replicas have no parameters() and a state_dict() without weights, and must still compute the
+    module's logits through the engine of their device."""
+    torch = torch_cuda
+    tag, name, cfg, sd, feats, z = load_golden_model("model_resnet__res8.npz")
+    model = _build(torch, name, cfg, sd)
+    x = torch.from_numpy(feats).cuda()
+    want = model(x)
+    try:
+        replicas = torch.nn.parallel.replicate(model, [0, 0])
+    except Exception as exc:   # noqa: BLE001
+        pytest.skip(f"replicate() onto one device twice is refused here: {exc!r}")
+    for r in replicas:
+        assert list(r.parameters()) == []
+        assert torch.equal(r(x), want)
+    assert len(model._engines) == 1
+
+
+def test_absurd_descriptions_come_back_as_error_codes(torch_cuda):
+    """include/kws.h: nothing throws across the ABI, and no size is allocated from before it is bounded: a depth of INT_MAX (whose
+    `+ 1` would wrap, or resize a vector to terabytes) or a width of 2^30 comes back as a code and a message."""
+    import ctypes
+    from honk2_amd import _lib
+    lib = _lib.load()
+    for kw in (dict(n_layers=2 ** 31 - 1, n_feature_maps=45), dict(n_layers=6, n_feature_maps=2 ** 30), dict(n_layers=6, n_feature_maps=45, freq=2 ** 30)):
+        h = ctypes.c_void_p()
+        d = _lib.make_desc(_lib.KWS_MODEL_RESNET, n_labels=12, pool_h=4, pool_w=3, **kw)
+        rc = lib.kws_create(ctypes.byref(d), ctypes.byref(h))
+        assert rc == _lib.KWS_EUNSUPPORTED and not h.value and b"out of range" in lib.kws_last_error(), (kw, rc)
+        with pytest.raises(RuntimeError):
+            _lib.Engine(d)
+
+
+def test_graph_replays_back_to_back_without_synchronisation(torch_cuda):
+    """Round 3 saw a GPU memory fault on un-synchronised back-to-back replays of the captured wav -> logits graph, when each
+    persistent kernel had a memset node in front of it that re-armed its work queue.  The queues now re-arm themselves (the
+    last workgroup to retire zeroes them: kws_internal.h queue_retire), so a replay is two kernel nodes and nothing else.  1 500
+    clips (more than the 512 resident workgroups, so the queue hands out most of them -- the 48-clip capture test never touches
+    it): four replays on new inputs with NO host synchronisation in between, each compared bit for bit with the eager call."""
+    torch = torch_cuda
+    from oracle import weights
+    tag, name, cfg, sd, feats, z = load_golden_model("model_resnet__res8.npz")
+    model = _build(torch, name, cfg, sd)
+    n = 1500
+    srcs = [torch.from_numpy(weights.make_waveforms(n, seed=40 + i)).cuda() for i in range(2)]
+    wants = [model.forward_wav(w).clone() for w in srcs]
+    assert model.plan_name() == "res8_fused"
+    static_in = srcs[0].clone()
+    out = torch.empty((n, cfg["n_labels"]), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        model.forward_wav(static_in, out=out)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            model.forward_wav(static_in, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    order = [1, 0, 1, 1]
+    outs = [torch.empty_like(out) for _ in order]
+    for slot, k in zip(outs, order):          # copy in, replay, copy out: stream-ordered, the host never waits
+        static_in.copy_(srcs[k])
+        graph.replay()
+        slot.copy_(out)
+    torch.cuda.synchronize()
+    for slot, k in zip(outs, order):
+        assert torch.equal(slot, wants[k]), float((slot - wants[k]).abs().max())
+    assert torch.equal(model.forward_wav(srcs[0]), wants[0])      # and the eager path finds the queues as it left them
+
+
 @pytest.mark.parametrize("fname", ["model_resnet__res8.npz", "model_cnn__cnn-tpool2.npz"])
 def test_plain_c_client_of_the_abi(torch_cuda, fname, tmp_path):
     """The drop-in boundary is a C ABI: tests/c_abi/kws_c_client.c (gcc, libkws_hip.so + the HIP runtime, no Python, no PyTorch; device
@@ -1119,3 +1212,56 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(torch_cuda, tmp_path):
                              "--batch", "2048", "--no-cpu-baseline", "--no-secondary"], env=env3, capture_output=True, text=True, timeout=600, cwd=root)
         assert sg.returncode == 0, sg.stderr[-2000:]
         assert np.array_equal(np.load(tmp_path / "n1g.npy"), a)
+    # RCCL itself, on the hardware this box has: the distributed leg as a fresh torchrun child with a ONE-rank nccl process group
+    # (KWS_FORCE_DIST): init_process_group("nccl"), the side-stream all_gather_into_tensor with its event hand-offs, barrier and the
+    # MAX all-reduce of the step time all execute on RCCL; the gathered logits must be the local ones, via the overlapped path
+    # (not the compute-stream fallback).
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env4 = dict(os.environ, KWS_FORCE_DIST="1", KWS_BENCH_DUMP=str(tmp_path / "n1r.npy"))
+    env4.pop("KWS_BENCH_BACKEND", None)
+    for steps in ("2", "3"):
+        rc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                             "--gpus", "1", "--steps", steps, "--warmup", "1", "--batch", "2048", "--no-cpu-baseline", "--no-secondary",
+                             "--no-shard", "--no-h2d"], env=env4, capture_output=True, text=True, timeout=600, cwd=root)
+        assert rc.returncode == 0, rc.stderr[-2000:]
+        liner = json.loads([ln for ln in rc.stdout.splitlines() if ln.startswith("{")][-1])
+        coll = liner["collective"]
+        assert coll["backend"] == "nccl" and coll["world_size"] == 1 and coll["forced_one_rank_group"]
+        assert coll["overlapped_on_side_stream"] and coll["overlap_fallback"] is None, coll
+        assert np.array_equal(np.load(tmp_path / "n1r.npy"), a)
+
+
+def test_entry_point_reduces_over_rccl_with_a_one_rank_group(torch_cuda, tmp_path):
+    """run/test.py:main under torchrun with a forced one-rank nccl process group: shard_loader, evaluate_partial and reduce_results'
+    all-reduce run on RCCL (reference: DataParallel, run/test.py:69-70); the result must equal the plain single-process evaluation."""
+    import subprocess
+    import sys
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = os.path.join(root, "tests", "configs", "res8_synthetic.json")
+    script = tmp_path / "run_eval.py"
+    script.write_text(
+        "import json, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import torch.distributed as dist\n"
+        "from honk2_amd.run import test as t\n"
+        "from honk2_amd.utils import load_json\n"
+        "res = t.main(load_json(sys.argv[1]))\n"
+        "info = {'backend': dist.get_backend() if dist.is_initialized() else None}\n"
+        "json.dump({'res': res, 'info': info}, open(sys.argv[2], 'w'))\n")
+    plain = subprocess.run([sys.executable, str(script), cfg, str(tmp_path / "plain.json")], capture_output=True, text=True, timeout=600, cwd=root)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    forced = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                             "--master-port", str(port), str(script), cfg, str(tmp_path / "forced.json")],
+                            env=dict(os.environ, KWS_FORCE_DIST="1"), capture_output=True, text=True, timeout=600, cwd=root)
+    assert forced.returncode == 0, forced.stderr[-2000:]
+    a, b = json.load(open(tmp_path / "plain.json")), json.load(open(tmp_path / "forced.json"))
+    assert a["info"]["backend"] is None and b["info"]["backend"] == "nccl"
+    assert a["res"]["metric_Acc"] == b["res"]["metric_Acc"] and a["res"].get("metric_PerClassAcc") == b["res"].get("metric_PerClassAcc")
+    assert abs(a["res"]["loss"] - b["res"]["loss"]) <= 1e-12 * max(1.0, abs(a["res"]["loss"]))

@@ -101,6 +101,20 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol(lib_built):
             _lib.Engine(d)
 
 
+def test_no_exception_crosses_the_c_abi(lib_built, monkeypatch):
+    """include/kws.h: "never throws across the ABI".  KWS_TEST_THROW makes kws_create's body throw (std::bad_alloc or a
+    std::runtime_error) in front of the device check, so this runs without a GPU: the guard around every entry point has to turn
+    it into a code + kws_last_error(), not into std::terminate under ctypes."""
+    d = _lib.make_desc(_lib.KWS_MODEL_NONE)
+    h = ctypes.c_void_p()
+    monkeypatch.setenv("KWS_TEST_THROW", "bad_alloc")
+    assert lib_built.kws_create(ctypes.byref(d), ctypes.byref(h)) == _lib.KWS_ENOMEM and not h.value
+    assert b"out of host memory" in lib_built.kws_last_error()
+    monkeypatch.setenv("KWS_TEST_THROW", "synthetic failure")
+    assert lib_built.kws_create(ctypes.byref(d), ctypes.byref(h)) == _lib.KWS_EINVAL and not h.value
+    assert b"synthetic failure" in lib_built.kws_last_error()
+
+
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "honk2_amd")):
         for f in files:
@@ -201,9 +215,39 @@ def test_streaming_dataset_matches_the_reference_class(tag, case):
     assert np.array_equal(stream[5 * shift:5 * shift + window], w5)
 
 
-def test_data_parallel_replicas_get_one_engine_per_device_and_never_close_each_others(monkeypatch):
-    """nn.DataParallel replicas are shallow __dict__ copies (reference multi-GPU mechanism, run/test.py:69-70): the replica
-    on cuda:1 must build its own engine and leave the one the cuda:0 replica is using alone."""
+def _replicate_like_torch(model):
+    """What torch.nn.parallel.replicate() makes of `model` for ONE device (torch 2.10, nn/parallel/replicate.py), with clones
+    standing in for the broadcast copies (no GPU here): every module is shallow-copied by _replicate_for_data_parallel() -- EMPTY
+    _parameters --, children are re-linked, each parameter copy is set as a PLAIN ATTRIBUTE and recorded in _former_parameters,
+    buffers are replaced by copies."""
+    modules = list(model.modules())
+    index = {m: i for i, m in enumerate(modules)}
+    copies = []
+    for m in modules:
+        r = m._replicate_for_data_parallel()
+        r._former_parameters = {}
+        copies.append(r)
+    for i, m in enumerate(modules):
+        r = copies[i]
+        for key, child in m._modules.items():
+            r._modules[key] = None if child is None else copies[index[child]]
+        for key, param in m._parameters.items():
+            if param is None:
+                r._parameters[key] = None
+            else:
+                c = param.detach().clone()
+                setattr(r, key, c)
+                r._former_parameters[key] = c
+        for key, buf in m._buffers.items():
+            r._buffers[key] = None if buf is None else buf.detach().clone()
+    return copies[0]
+
+
+@pytest.mark.parametrize("family", ["ResNet", "CNN"])
+def test_data_parallel_replicas_get_one_engine_per_device_and_never_close_each_others(monkeypatch, family):
+    """nn.DataParallel replicas (reference multi-GPU mechanism, run/test.py:69-70) have no parameters() and a state_dict() without
+    the weights (see _replicate_like_torch): the replica on cuda:1 must still build its own engine, load it with ALL tensors of the
+    module it was made from, key the upload on that module's tensor versions, and leave the cuda:0 engine alone."""
     from honk2_amd.model import model_utils
 
     class FakeEngine:
@@ -211,11 +255,11 @@ def test_data_parallel_replicas_get_one_engine_per_device_and_never_close_each_o
 
         def __init__(self, desc, device):
             self.device = torch.device(device)
-            self.loaded = 0
+            self.loaded = []
             FakeEngine.created.append(self)
 
         def load_tensor(self, name, tensor):
-            self.loaded += 1
+            self.loaded.append(name)
 
         def close(self):
             FakeEngine.closed.append(self)
@@ -224,21 +268,34 @@ def test_data_parallel_replicas_get_one_engine_per_device_and_never_close_each_o
     monkeypatch.setattr(model_utils._lib, "Engine", FakeEngine)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "current_device", lambda: current["index"])
-    cfg = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 12}
-    model = find_cls("model.ResNet")(dict(cfg)).eval()
-    replica = model._replicate_for_data_parallel()       # what torch.nn.parallel.replicate does per device
-    replica._parameters, replica._buffers, replica._modules = model._parameters, model._buffers, model._modules
+    if family == "ResNet":
+        cfg = {"pool": [4, 3], "n_feature_maps": 45, "n_layers": 6, "use_dilation": False, "n_labels": 12}
+    else:
+        cfg = {"time": 101, "frequency": 40, "dropout_prob": 0.5, "n_labels": 12,
+               "conv_0": {"out_channels": 64, "kernel_size": [20, 8], "stride": [1, 1]}, "pool_0": {"kernel_size": [2, 2]},
+               "conv_1": {"out_channels": 64, "kernel_size": [10, 4], "stride": [1, 1]}, "pool_1": {"kernel_size": [1, 1]}}
+    model = find_cls(f"model.{family}")(dict(cfg)).eval()
+    names = list(model.state_dict())
+    replica = _replicate_like_torch(model)
+    assert list(replica.parameters()) == [] and len(replica.state_dict()) < len(names)     # what broke engine() before
     e0 = model.engine()
     current["index"] = 1
     e1 = replica.engine()
     current["index"] = 0
     assert e0 is not e1 and (e0.device.index, e1.device.index) == (0, 1)
+    assert e0.loaded == names and e1.loaded == names                      # the replica's engine got every tensor
     assert model.engine() is e0 and FakeEngine.closed == [] and len(FakeEngine.created) == 2
-    n = e0.loaded
-    assert model.engine() is e0 and e0.loaded == n          # unchanged weights are not uploaded again
+    assert model.engine() is e0 and e0.loaded == names                    # unchanged weights are not uploaded again
+    # the next forward of DataParallel makes NEW replicas (fresh copies, possibly at recycled addresses, all at version 0): no re-upload ...
+    current["index"] = 1
+    replica2 = _replicate_like_torch(model)
+    assert replica2.engine() is e1 and e1.loaded == names
+    # ... until the SOURCE module's weights change: then every device's engine reloads, whatever the copies' addresses are
     with torch.no_grad():
-        next(model.parameters()).add_(1.0)                  # a new version -> re-upload, on that device's engine only
-    assert model.engine() is e0 and e0.loaded == 2 * n and e1.loaded == n
+        next(model.parameters()).add_(1.0)
+    assert _replicate_like_torch(model).engine() is e1 and e1.loaded == 2 * names
+    current["index"] = 0
+    assert model.engine() is e0 and e0.loaded == 2 * names
 
 
 def test_bench_parity_sample_is_spread_in_every_prefix():

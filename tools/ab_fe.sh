@@ -1,5 +1,5 @@
 # A/B of front-end library variants: tools/ab_fe.sh <variant> [<variant> ...]  (honk2_amd/variants/lib_<name>.so; "default" = the built library)
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 V=$PWD/honk2_amd/variants
 for rep in 1 2; do

@@ -1,5 +1,5 @@
 # A/B of the per-model table rows: tools/ab_models.sh <variant> -- models...   (KWS_BENCH_DTYPE / KWS_BENCH_BATCH from the environment)
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 v=$1; shift
 for n in prev new prev new; do

@@ -1,5 +1,5 @@
 # A/B of fused-res8 library variants: tools/ab_r8.sh <variant> [<variant> ...]  (names under honk2_amd/variants/lib_<name>.so; "default" = the built library)
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 V=$PWD/honk2_amd/variants
 for rep in 1 2; do

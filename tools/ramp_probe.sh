@@ -1,5 +1,5 @@
 # does a short measurement under-state the shard's rate?  the same 8 192-clip launches timed over 10, 50, 250 and 1000 repetitions
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 export FE_SETTLE_S=0 R8_SETTLE_S=0     # from idle: that is the point
 for r in 10 50 250 1000; do FE_B=8192 FE_REPS=$r FE_TAG=reps$r timeout -k 10 120 python tools/fe_time.py | cut -c1-70; done
