@@ -21,7 +21,7 @@ DTYPES = {"f32": KWS_DTYPE_F32, "fp32": KWS_DTYPE_F32, "float32": KWS_DTYPE_F32,
 # every symbol include/kws.h declares (tests check the library exports exactly these)
 EXPORTS = (
     "kws_create", "kws_destroy", "kws_load_weights", "kws_workspace_bytes", "kws_set_workspace", "kws_num_frames",
-    "kws_mfcc", "kws_mfcc_pcm16", "kws_forward", "kws_forward_wav", "kws_forward_pcm16", "kws_workspace_bytes_windows", "kws_mfcc_windows", "kws_forward_windows", "kws_eval_batch", "kws_plan_name", "kws_profile_enable",
+    "kws_mfcc", "kws_mfcc_pcm16", "kws_forward", "kws_forward_wav", "kws_forward_pcm16", "kws_workspace_bytes_windows", "kws_mfcc_windows", "kws_forward_windows", "kws_eval_batch", "kws_plan_name", "kws_plan_detail", "kws_profile_enable",
     "kws_profile_read", "kws_last_error", "kws_abi_version",
 )
 
@@ -94,6 +94,8 @@ def load():
     lib.kws_eval_batch.restype = ci
     lib.kws_plan_name.argtypes = [vp]
     lib.kws_plan_name.restype = C.c_char_p
+    lib.kws_plan_detail.argtypes = [vp]
+    lib.kws_plan_detail.restype = C.c_char_p
     lib.kws_profile_enable.argtypes = [vp, ci]
     lib.kws_profile_enable.restype = ci
     lib.kws_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(ci)]
@@ -337,6 +339,9 @@ class Engine:
 
     def plan_name(self):
         return self.lib.kws_plan_name(self.handle).decode()
+
+    def plan_detail(self):
+        return self.lib.kws_plan_detail(self.handle).decode()
 
     def profile_enable(self, on=True):
         check(self.lib.kws_profile_enable(self.handle, int(bool(on))), "kws_profile_enable")

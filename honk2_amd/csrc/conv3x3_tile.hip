@@ -827,6 +827,370 @@ hipError_t launch_conv3x3_pair(const PairConvParams& p, int C, hipStream_t s) {
     return p.f16 ? launch_pair_k<true, 3, 2>(p, s) : launch_pair_k<false, 3, 2>(p, s);
 }
 
+// ------------------------------------------------------------------------------------------------ three layers in one kernel
+// A run of THREE layers of equal dilation (res15: (4,5,6) d = 2, (7,8,9) d = 4, (10,11,12) d = 8; every run of hey_snips) on 16-bit
+// tensors, reference model/resnet.py:20-26, 46-55.  The pair kernel above, one layer deeper: the input tile is staged with a halo of
+// THREE rows, the first layer is computed on the output tile + two halo rows into a second LDS region, the second on the tile + one
+// row into a third, the last on the tile.  Every intermediate value is rounded to the tensor type exactly as the store it replaces,
+// so the result is bit-identical to one kernel per layer.  What the residual stream needs, by the parity of the first layer a:
+//   a even:  x_a = relu(conv_a(in)) + x_{a-2}: the residual comes from MEMORY (tile + two halo rows, in the layout it was written in,
+//            cells through the table); x_a is conv_{a+1}'s input and conv_{a+2}'s residual and never leaves the CU; the map of
+//            y_{a+1} reuses the input tile's LDS (dead after the first k-loop).
+//   a odd:   x_{a+1} = relu(conv_{a+1}(y_a)) + in: the residual is the staged tile; x_{a+1} feeds conv_{a+2} from LDS AND is stored
+//            (tile positions only, in the input's own layout: cell = flattened position) as the next even layer's residual.
+// Per run of res15: one staged read of 1.2 - 1.7 x the tile (+ 1.1 - 1.4 x of residual, a even) and one or two stored tensors, where a
+// single layer + a pair move 5 - 6 tensor passes; the first / second layer's halo rows are computed three / two times (the matrix pipe is
+// a quarter busy in these layers).
+template <int JT>
+__device__ __forceinline__ void triple_decode(int P_first, const TripleConvParams& p, float inv_cpc, int (&q)[JT], int (&pb)[JT]) {
+    // cell-in-clip and clip of positions P_first, P_first + 16, ...: one division, then steps of 16 (cpc_in >= 16: launcher).  Halo
+    // positions in front of the tensor are negative: whole clips are added first (their entries are never used, only in range)
+    int r;
+    int b = fdiv(P_first + p.wrap_clips * p.cpc_in, p.cpc_in, inv_cpc, r) - p.wrap_clips;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        q[j] = r;
+        pb[j] = b;
+        r += 16;
+        if (r >= p.cpc_in) {
+            r -= p.cpc_in;
+            ++b;
+        }
+    }
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 cl_unpack4(u32x2 rw) {
+    f32x4 rv;
+    if (F16) {   // (scalar conversions on purpose: see conv3x3_tile_kernel)
+        rv[0] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[0] & 0xffffu));
+        rv[1] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[0] >> 16));
+        rv[2] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[1] & 0xffffu));
+        rv[3] = (float)__builtin_bit_cast(_Float16, (unsigned short)(rw[1] >> 16));
+    } else {
+        rv = (f32x4){lo_f(rw[0]), hi_f(rw[0]), lo_f(rw[1]), hi_f(rw[1])};
+    }
+    return rv;
+}
+
+// JT1 / JT2 / JTB: position tiles per wave in the three phases (64 JT1 >= TILE + 4 halo, 64 JT2 >= TILE + 2 halo, TILE = 64 JTB)
+template <bool F16, int JT1, int JT2, int JTB, bool EVEN, int WGS>
+__global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvParams p) {
+    constexpr int NB = 6, MT = 3, CELL = NB * 16, STEPS = (9 * NB + 3) / 4, NT = 256;
+    constexpr int TILE_P = 64 * JTB;
+    constexpr int NQ = NB, NGRP = NT / NQ;
+    extern __shared__ __align__(16) char lds[];
+    if (range_gate_closed(p.rg)) return;
+    t3_require_lds_base_zero(lds);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, pcol = lane & 15;
+    const int Ws = p.Ws, halo = Ws + 1;
+    int tile_id = (int)blockIdx.x;
+    {   // blocks that share an XCD take a contiguous run of tiles (halo re-reads hit that L2)
+        const int nwg = (int)gridDim.x, xcd = tile_id & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile_id >> 3);
+    }
+    const int P0 = tile_id * TILE_P;
+    // cells of the input tile [P0 - 3 halo, ..), of the first layer's map [P0 - 2 halo, ..), of the second layer's [P0 - halo, ..)
+    const int n_in = TILE_P + 6 * halo, n_m1 = TILE_P + 4 * halo, n_m2 = TILE_P + 2 * halo;
+    // LDS: [zero cell][input tile][map 1][map 2 -- a even: over the input tile][k-step table 512 B][3 border tables]
+    const int mid1_off = (n_in + 1) * CELL;
+    const int mid2_off = EVEN ? CELL : mid1_off + n_m1 * CELL;
+    const int tab_off = EVEN ? mid1_off + n_m1 * CELL : mid2_off + n_m2 * CELL;
+    const int border_off = tab_off + 512;           // [3][16 classes][NB*8] floats
+    const float inv_cpc = 1.0f / (float)p.cpc_in;
+
+    // ---- table entries of this lane's positions in the three phases (requested first, consumed after the staging loads are out)
+    // (the entries of the second and third phase are requested behind the k-loop in front of them: they would only occupy registers until then)
+    int q1[JT1], b1[JT1];
+    triple_decode<JT1>(P0 - 2 * halo + w * JT1 * 16 + pcol, p, inv_cpc, q1, b1);
+    int pe1[JT1], pr1[EVEN ? JT1 : 1], pe2[JT2];
+    int pe3m[JTB], pe3o[JTB], b3[JTB];
+#pragma unroll
+    for (int j = 0; j < JT1; ++j) {
+        if (EVEN) {
+            const i32x4 e = *reinterpret_cast<const i32x4*>(p.postab + 4 * q1[j]);
+            pe1[j] = e[0];
+            pr1[EVEN ? j : 0] = e[2];
+        } else {
+            pe1[j] = p.postab[4 * q1[j]];
+        }
+    }
+
+    // ---- stage cells [P0 - 3 halo, P0 + TILE_P + 3 halo), tables
+    {
+        const int qd = tid % NQ, grp = tid / NQ;
+        if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+        if (tid < 4 * (STEPS + 2)) {
+            const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
+            reinterpret_cast<int2_*>(lds + tab_off)[tid] = (int2_){((ty - 1) * Ws + (tx - 1)) * CELL + cblk * 16, tap < 9 ? tap : 31};
+        }
+        for (int t = tid; t < 3 * 32 * NB; t += NT) {
+            const int which = t / (32 * NB), r = t - which * 32 * NB;
+            const float* src = p.border[which];
+            f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (src) bv = *reinterpret_cast<const f32x4*>(src + 4 * r);
+            *reinterpret_cast<f32x4*>(lds + border_off + 16 * t) = bv;
+        }
+        if (grp < NGRP) {
+            const char* src = reinterpret_cast<const char*>(p.in);
+            constexpr int UNR = 10;   // all of a thread's loads in flight together
+            for (int i0 = grp; i0 < n_in; i0 += UNR * NGRP) {
+                f32x4 v[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int q = min(max(P0 - 3 * halo + i0 + u * NGRP, 0), p.total - 1);   // (cells that are never tapped: clamped, not tested)
+                    v[u] = (p.debug & 2) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * CELL + qd * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int i = i0 + u * NGRP;
+                    if (i < n_in) *reinterpret_cast<f32x4*>(lds + (i + 1) * CELL + qd * 16) = v[u];
+                }
+            }
+        }
+    }
+    const int abytes = STEPS * MT * (F16 ? 2 : 3) * 1024;
+    const __amdgpu_buffer_rsrc_t ars_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk[0]), 0, abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk[1]), 0, abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk[2]), 0, abytes, 0x00020000);
+    u32x4 afirst[MT];
+    pair_first_frags<MT, F16>(ars_a, lane * 16, afirst);   // in flight across the barrier
+
+    // ---- a even: the first layer's residual x_{a-2} at this lane's cells of map 1 (requested now, consumed after the first k-loop)
+    int tmask1[JT1];
+#pragma unroll
+    for (int j = 0; j < JT1; ++j) {
+        const int lm = (w * JT1 + j) * 16 + pcol;
+        const int Pm = P0 - 2 * halo + lm;
+        tmask1[j] = (lm < n_m1 && Pm >= 0 && Pm < p.total) ? pe1[j] : 0;   // outside: no live tap, no store, never read by the next layer either
+    }
+    u32x2 resh[EVEN ? JT1 : 1][MT];
+    if (EVEN) {
+        const char* const resp = reinterpret_cast<const char*>(p.res);
+#pragma unroll
+        for (int j = 0; j < JT1; ++j) {
+            const size_t rcell = (size_t)(b1[j] * p.cpc_res + pr1[EVEN ? j : 0]) * CELL;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                resh[EVEN ? j : 0][m] = (u32x2){0u, 0u};
+                if ((tmask1[j] >> 13) & 1) resh[EVEN ? j : 0][m] = *reinterpret_cast<const u32x2*>(resp + rcell + (m * 16 + 4 * g) * 2);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int2_* const ktab = reinterpret_cast<const int2_*>(lds + tab_off) + g;
+    float amax = 0.f;
+    // ---------------------------------------------------------------- layer a on map 1's cells -> LDS
+    {
+        int lbase[JT1];
+#pragma unroll
+        for (int j = 0; j < JT1; ++j) lbase[j] = ((w * JT1 + j) * 16 + pcol + halo + 1) * CELL;   // its cell in the input tile (behind the zero cell)
+        f32x4 acc[JT1][MT];
+        if (p.debug & 1) {
+#pragma unroll
+            for (int j = 0; j < JT1; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else
+            pair_kloop<NB, MT, F16, JT1>(lds, ktab, ars_a, lane * 16, afirst, lbase, tmask1, acc);
+        pair_first_frags<MT, F16>(ars_b, lane * 16, afirst);   // the next layer's first fragments: in flight across the epilogue and the barrier
+        {
+            int q2[JT2], b2[JT2];
+            triple_decode<JT2>(P0 - halo + w * JT2 * 16 + pcol, p, inv_cpc, q2, b2);
+#pragma unroll
+            for (int j = 0; j < JT2; ++j) pe2[j] = p.postab[4 * q2[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < JT1; ++j) {
+            if (!((tmask1[j] >> 13) & 1)) continue;     // (outside the tensor / padding of a partial sub-map: every tap that would land here is dead in the consumer's mask)
+            const int lm = (w * JT1 + j) * 16 + pcol;
+            const int bmask = (tmask1[j] >> 9) & 15;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = m * 16 + 4 * g;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(lds + border_off + (bmask * (NB * 8) + co0) * 4);
+                f32x4 rv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (EVEN) rv = cl_unpack4<F16>(resh[EVEN ? j : 0][m]);
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = relu1(fmaf(acc[j][m][r], p.inv_scale[0], bb[r])) + rv[r];   // (x + 0 = x exactly for x >= +0: the same bits as the store without a residual)
+                    amax = fmaxf(amax, fabsf(v[r]));
+                }
+                *reinterpret_cast<u32x2*>(lds + mid1_off + lm * CELL + co0 * 2) = cl_pack4<F16>(v);
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- layer a + 1 on map 2's cells -> LDS (a odd: + the staged input, and -> out2)
+    {
+        int lbase[JT2], tmask[JT2];
+#pragma unroll
+        for (int j = 0; j < JT2; ++j) {
+            const int lm = (w * JT2 + j) * 16 + pcol;
+            const int Pm = P0 - halo + lm;
+            lbase[j] = mid1_off + (lm + halo) * CELL;
+            tmask[j] = (lm < n_m2 && Pm >= 0 && Pm < p.total) ? pe2[j] : 0;
+        }
+        f32x4 acc[JT2][MT];
+        if (p.debug & 64) {
+#pragma unroll
+            for (int j = 0; j < JT2; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else
+            pair_kloop<NB, MT, F16, JT2>(lds, ktab, ars_b, lane * 16, afirst, lbase, tmask, acc);
+        pair_first_frags<MT, F16>(ars_c, lane * 16, afirst);
+        {
+            int q3[JTB];
+            triple_decode<JTB>(P0 + w * JTB * 16 + pcol, p, inv_cpc, q3, b3);
+#pragma unroll
+            for (int j = 0; j < JTB; ++j) {
+                const int2_ e = *reinterpret_cast<const int2_*>(p.postab + 4 * q3[j]);
+                pe3m[j] = e[0];
+                pe3o[j] = e[1];
+            }
+        }
+        char* const out2p = reinterpret_cast<char*>(p.out2);
+#pragma unroll
+        for (int j = 0; j < JT2; ++j) {
+            if (!((tmask[j] >> 13) & 1)) continue;
+            const int lm = (w * JT2 + j) * 16 + pcol;
+            const int bmask = (tmask[j] >> 9) & 15;
+            const bool own = lm >= halo && lm < halo + TILE_P;        // a position of this workgroup's output tile
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = m * 16 + 4 * g;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(lds + border_off + ((16 + bmask) * (NB * 8) + co0) * 4);
+                f32x4 rv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!EVEN) rv = cl_unpack4<F16>(*reinterpret_cast<const u32x2*>(lds + (lm + 2 * halo + 1) * CELL + co0 * 2));   // x_{a-1} at this position
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = relu1(fmaf(acc[j][m][r], p.inv_scale[1], bb[r])) + rv[r];
+                    amax = fmaxf(amax, fabsf(v[r]));
+                }
+                const u32x2 pk = cl_pack4<F16>(v);
+                *reinterpret_cast<u32x2*>(lds + mid2_off + lm * CELL + co0 * 2) = pk;
+                if (!EVEN && own && !(p.debug & 4)) *reinterpret_cast<u32x2*>(out2p + (size_t)(P0 - halo + lm) * CELL + co0 * 2) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- layer a + 2 from map 2 (a even: + x_a from map 1) -> memory
+    {
+        int lbase[JTB], tmask[JTB];
+#pragma unroll
+        for (int j = 0; j < JTB; ++j) {
+            const int local = (w * JTB + j) * 16 + pcol;
+            lbase[j] = mid2_off + (local + halo) * CELL;
+            tmask[j] = P0 + local < p.total ? pe3m[j] : 0;
+        }
+        f32x4 acc[JTB][MT];
+        if (p.debug & 128) {
+#pragma unroll
+            for (int j = 0; j < JTB; ++j)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        } else
+            pair_kloop<NB, MT, F16, JTB>(lds, ktab, ars_c, lane * 16, afirst, lbase, tmask, acc);
+        char* const outp = reinterpret_cast<char*>(p.out);
+#pragma unroll
+        for (int j = 0; j < JTB; ++j) {
+            if (!((tmask[j] >> 13) & 1)) continue;
+            const int local = (w * JTB + j) * 16 + pcol;
+            const int bmask = (tmask[j] >> 9) & 15;
+            const size_t ocell = (size_t)(b3[j] * p.cpc_out + pe3o[j]) * CELL;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int co0 = m * 16 + 4 * g;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(lds + border_off + ((32 + bmask) * (NB * 8) + co0) * 4);
+                f32x4 rv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (EVEN) rv = cl_unpack4<F16>(*reinterpret_cast<const u32x2*>(lds + mid1_off + (local + 2 * halo) * CELL + co0 * 2));   // x_a at this position
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = relu1(fmaf(acc[j][m][r], p.inv_scale[2], bb[r])) + rv[r];
+                    amax = fmaxf(amax, fabsf(v[r]));
+                }
+                if (!(p.debug & 4)) *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
+            }
+        }
+    }
+    range_note(p.rg, amax);
+}
+
+// LDS bytes of the triple kernel for sub-maps Ws cells wide and TILE output positions per workgroup
+static size_t conv3x3_triple_lds_bytes(int Ws, int tile, bool even) {
+    const int halo = Ws + 1;
+    const int cells = 1 + (tile + 6 * halo) + (tile + 4 * halo) + (even ? 0 : tile + 2 * halo);
+    return (size_t)cells * 96 + 512 + 3 * 16 * 48 * 4;
+}
+// configurations built: 0 = none; 1: TILE 192, 4 + 4 tiles per wave in the first two phases, three workgroups per CU; 2: TILE 256, 5 + 5, two;
+// 3: TILE 192, 4 + 4, two; 4: TILE 192, 5 + 4, two (halo rows up to 32 cells)
+static int conv3x3_triple_config(int Ws, bool even) {
+    static const int forced = std::getenv("KWS_T3_TRIPLE_CFG") ? std::atoi(std::getenv("KWS_T3_TRIPLE_CFG")) : 0;   // A/B knob
+    const int halo = Ws + 1;
+    auto fits = [&](int cfg) {
+        switch (cfg) {
+            case 1: return 192 + 4 * halo <= 256 && conv3x3_triple_lds_bytes(Ws, 192, even) <= 53 * 1024;
+            case 2: return 256 + 4 * halo <= 320 && conv3x3_triple_lds_bytes(Ws, 256, even) <= 80 * 1024 - 256;
+            case 3: return 192 + 4 * halo <= 256 && conv3x3_triple_lds_bytes(Ws, 192, even) <= 80 * 1024 - 256;
+            case 4: return 192 + 4 * halo <= 320 && 192 + 2 * halo <= 256 && conv3x3_triple_lds_bytes(Ws, 192, even) <= 80 * 1024 - 256;
+        }
+        return false;
+    };
+    if (forced && fits(forced)) return forced;
+    for (int cfg = 1; cfg <= 4; ++cfg)
+        if (fits(cfg)) return cfg;
+    return 0;
+}
+bool conv3x3_triple_supported(int C, int Ws, bool first_even) { return (C + 7) / 8 * 8 == 48 && conv3x3_triple_config(Ws, first_even) != 0; }
+
+template <bool F16, int JT1, int JT2, int JTB, bool EVEN, int WGS>
+static hipError_t launch_triple_k(const TripleConvParams& p, hipStream_t s) {
+    constexpr int tile = 64 * JTB;
+    const unsigned grid = (unsigned)((p.total + tile - 1) / tile);
+    const size_t lds = conv3x3_triple_lds_bytes(p.Ws, tile, EVEN);
+    auto k = conv3x3_triple_kernel<F16, JT1, JT2, JTB, EVEN, WGS>;
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
+        hipError_t e = allow_big_lds_at_base_zero(reinterpret_cast<const void*>(k));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+template <bool F16, bool EVEN>
+static hipError_t launch_triple_cfg(const TripleConvParams& p, int cfg, hipStream_t s) {
+    switch (cfg) {
+        case 1: return launch_triple_k<F16, 4, 4, 3, EVEN, 3>(p, s);
+        case 2: return launch_triple_k<F16, 5, 5, 4, EVEN, 2>(p, s);
+        case 3: return launch_triple_k<F16, 4, 4, 3, EVEN, 2>(p, s);
+        case 4: return launch_triple_k<F16, 5, 4, 3, EVEN, 2>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv3x3_triple(const TripleConvParams& p_in, int C, hipStream_t s) {
+    if (p_in.total <= 0) return hipSuccess;
+    TripleConvParams p = p_in;
+    const bool even = p.first_even != 0;
+    const int cfg = (C + 7) / 8 * 8 == 48 ? conv3x3_triple_config(p.Ws, even) : 0;
+    const int halo = p.Ws + 1;
+    p.wrap_clips = (3 * halo + p.cpc_in - 1) / std::max(p.cpc_in, 1);
+    // positions are decoded with fp32 reciprocals (exact below 2^24), byte offsets are 32-bit, a wave steps through the table 16 cells at a time
+    if (!cfg || p.cpc_in < 16 || (long long)p.total + (long long)(p.wrap_clips + 1) * p.cpc_in + 384 + 6 * halo >= (1 << 24) ||
+        (long long)p.total * 96 >= (1LL << 31) || (long long)p.B * std::max(p.cpc_out, p.cpc_res) * 96 >= (1LL << 31) ||
+        (even ? (p.res == nullptr || p.out2 != nullptr) : (p.out2 == nullptr || p.res != nullptr)))
+        return hipErrorInvalidValue;
+    if (p.f16) return even ? launch_triple_cfg<true, true>(p, cfg, s) : launch_triple_cfg<true, false>(p, cfg, s);
+    return even ? launch_triple_cfg<false, true>(p, cfg, s) : launch_triple_cfg<false, false>(p, cfg, s);
+}
+
 // ------------------------------------------------------------------------------------------------ fp32 NCHW -> CL
 // (B, C, H, W) fp32 -> pooled (window kh x kw, stride = window, floor; mode 0 average, 1 max; 1 x 1 = plain transpose)
 // channels-last (B, H/kh, W/kw, cp) fp32, i.e. layout(1).  One thread: one output position x four channels.

@@ -76,6 +76,7 @@ struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the l
     // still be reading its table when the next clip length arrives)
     struct PosTab { DevMem mem; int cpc[3] = {0, 0, 0}; };
     std::map<int, std::unique_ptr<PosTab>> postabs;
+    std::map<int, std::unique_ptr<PosTab>> postabs3;   // the same for a run of three layers starting here (conv3x3_triple_kernel)
     // apk16h: fp16 fragments of the generic kernel; w9cl: conv_0 as [9 taps][C padded to 8] (conv0_cl_kernel)
     float x_scale = 1.f;     // 2^S of apk16h   // apk_t3h: fp16 fragments of the tiled 3x3 kernel
     float t3h_scale = 1.f;   // 2^S of apk_t3h   // border_pad: rows padded to a multiple of 8 channels (tiled kernel)
@@ -146,6 +147,9 @@ struct kws_handle {
     // workspace
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    std::string plan_detail;               // tiled ResNet plan: what the last call launched per chunk (kws_plan_detail)
+    int plan_detail_T = -1;
+    int t3_triple = 1;                     // runs of three equal-dilation layers in one kernel (KWS_T3_TRIPLE=0: pairs + singles; 2: any three consecutive layers)
     bool t3_pair = true;                   // tiled plan, 16-bit tensors: consecutive layers of equal dilation in one kernel (KWS_T3_PAIR=0: off)
     DevMem r8_shift;                       // fused res8, kws_forward: per-clip power-of-two shifts of caller-provided features (feat_shift_kernel)
     DevMem range_flag;                     // device words: [0] fp16 range guard of the layer-wise plans (kws_internal.h), [16] /
@@ -723,9 +727,18 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
     float* X2 = (float*)ws; ws += align256(cl * cb * 4);
     float* Y = (float*)ws;
     int rc;
+    const bool note = h->plan_detail_T != T;     // (once per clip length: the launch sequence depends on nothing else)
+    std::string detail = "conv0";
+    auto note_layers = [&](const char* what, int i0, int n) {
+        if (!note) return;
+        detail += std::string(" ") + what + "(";
+        for (int u = 0; u < n; ++u) detail += (u ? "," : "") + std::to_string(i0 + u);
+        detail += ")";
+    };
     for (int b0 = 0; b0 < B; b0 += cb) {
         const int nb = std::min(cb, B - b0);
         auto pass = [&](int terms, RangeGate rg) -> int {
+            const bool first_pass = b0 == 0 && !rg.gated;
             // conv_0 + ReLU (+ AvgPool) in plain fp32, straight into the channels-last tensor; with single-term products (the
             // `bf16` / `fp16` dtypes) the tensors between the layers hold the 16-bit operand type itself
             int m_f16, m_terms;
@@ -741,6 +754,52 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                 const int ld_out = i < d.n_layers ? ilog2(resnet_dilation(d, i + 1)) : 0;
                 const int dd = 1 << ld_in;
                 const bool even = (i % 2) == 0;
+                // a run of exactly three layers of one dilation (res15: (4,5,6) (7,8,9) (10,11,12)), 16-bit tensors: one kernel for the run
+                // (t3_triple == 2, A/B runs: any three consecutive layers of one dilation)
+                const int Hs_i = (sh.H + dd - 1) / dd, Ws_i = (sh.W + dd - 1) / dd;
+                if (m_terms == 1 && h->t3_pair && h->t3_triple && i + 2 <= d.n_layers && resnet_dilation(d, i + 1) == dd &&
+                    resnet_dilation(d, i + 2) == dd &&
+                    (h->t3_triple == 2 || ((i == 1 || resnet_dilation(d, i - 1) != dd) && (i + 3 > d.n_layers || resnet_dilation(d, i + 3) != dd))) &&
+                    dd * dd * Hs_i * Ws_i >= 16 && conv3x3_triple_supported(C, Ws_i, even)) {
+                    const int ld_out3 = i + 2 < d.n_layers ? ilog2(resnet_dilation(d, i + 3)) : 0;
+                    std::unique_ptr<ConvLayer::PosTab>& pt3 = h->rconv[i].postabs3[T];
+                    if (!pt3) {
+                        std::vector<int> tab;
+                        std::unique_ptr<ConvLayer::PosTab> fresh(new ConvLayer::PosTab);
+                        build_tile_conv_table(sh.H, sh.W, ld_in, ld_out3, ld_x, tab, fresh->cpc[0], fresh->cpc[1], fresh->cpc[2]);
+                        if ((rc = fresh->mem.upload(tab.data(), tab.size() * sizeof(int)))) { h->rconv[i].postabs3.erase(T); return rc; }
+                        pt3 = std::move(fresh);
+                    }
+                    TripleConvParams tp3{};
+                    tp3.first_even = even ? 1 : 0;
+                    tp3.in = even ? Y : xc;
+                    tp3.res = even ? xc : nullptr;
+                    tp3.out = even ? xn : Y;
+                    tp3.out2 = even ? nullptr : xn;
+                    tp3.f16 = m_f16;
+                    for (int u = 0; u < 3; ++u) {
+                        const ConvLayer& L = h->rconv[i + u];
+                        tp3.apk[u] = m_f16 ? L.apk_t3h.as<unsigned short>() : L.apk16.as<unsigned short>();
+                        tp3.inv_scale[u] = m_f16 ? 1.0f / L.t3h_scale : 1.0f;
+                        tp3.border[u] = L.has_border ? L.border_pad.as<float>() : nullptr;
+                    }
+                    tp3.B = nb; tp3.H = sh.H; tp3.W = sh.W; tp3.Cout = C;
+                    tp3.ld = ld_in; tp3.ld_out = ld_out3;
+                    tp3.Hs = Hs_i; tp3.Ws = Ws_i;
+                    tp3.total = nb * dd * dd * Hs_i * Ws_i;
+                    tp3.rg = rg;
+                    tp3.postab = pt3->mem.as<int>();
+                    tp3.cpc_in = pt3->cpc[0]; tp3.cpc_out = pt3->cpc[1]; tp3.cpc_res = pt3->cpc[2];
+                    static const int triple_dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
+                    tp3.debug = triple_dbg;
+                    HIP_TRY(launch_conv3x3_triple(tp3, C, s));
+                    if (first_pass) note_layers("triple", i, 3);
+                    // a even: x_{a+2} went to xn in the next run's layout; a odd: x_{a+1} went to xn in THIS run's layout (y_{a+2} is in Y)
+                    std::swap(xc, xn);
+                    ld_x = even ? ld_out3 : ld_in;
+                    i += 2;
+                    continue;
+                }
                 // odd i and i + 1 with the same dilation, 16-bit tensors: one kernel for both (y_i never leaves the CU)
                 if (!even && m_terms == 1 && h->t3_pair && i + 1 <= d.n_layers && resnet_dilation(d, i + 1) == dd &&
                     conv3x3_pair_tile(C, (sh.W + dd - 1) / dd) > 0) {
@@ -772,6 +831,7 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                     static const int pair_dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
                     pp.debug = pair_dbg;
                     HIP_TRY(launch_conv3x3_pair(pp, C, s));
+                    if (first_pass) note_layers("pair", i, 2);
                     std::swap(xc, xn);
                     ld_x = ld_out2;
                     ++i;
@@ -813,6 +873,7 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                     tp.dbg_ts = t3_buf.as<unsigned long long>();
                 }
                 HIP_TRY(launch_conv3x3_tile(tp, C, s));
+                if (first_pass) note_layers("conv", i, 1);
                 if (t3_this) {
                     std::vector<unsigned long long> z((size_t)8192 * 4 * 8);
                     HIP_TRY(hipStreamSynchronize(s));
@@ -835,6 +896,10 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
             return KWS_OK;
         };
         if ((rc = run_guarded(h, dtype_terms(d.dtype), s, pass))) return rc;
+    }
+    if (note && B > 0) {
+        h->plan_detail = detail + " mean+linear";
+        h->plan_detail_T = T;
     }
     return KWS_OK;
 }
@@ -1184,6 +1249,7 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
         if (std::strcmp(lw, "fp32") == 0) h->lw_mode = LW_FP32;
         else if (std::strcmp(lw, "nchw") == 0) h->lw_mode = LW_NCHW;
     }
+    if (const char* tp = std::getenv("KWS_T3_TRIPLE")) h->t3_triple = std::atoi(tp);
     if (const char* tp = std::getenv("KWS_T3_PAIR")) h->t3_pair = std::atoi(tp) != 0;   // A/B and tests: 0 = one kernel per layer
     int rc = setup_frontend(h.get());
     if (rc) return rc;
@@ -1521,6 +1587,10 @@ int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target
 }
 
 const char* kws_plan_name(const kws_handle* h) { return h ? h->last_plan : "none"; }
+const char* kws_plan_detail(const kws_handle* h) {
+    if (!h) return "none";
+    return (h->last_plan && std::strcmp(h->last_plan, "resnet_tiled") == 0 && !h->plan_detail.empty()) ? h->plan_detail.c_str() : h->last_plan;
+}
 
 int kws_profile_enable(kws_handle* h, int enable) {
     return guarded<int>([&]() -> int {

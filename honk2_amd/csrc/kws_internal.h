@@ -375,6 +375,33 @@ struct PairConvParams {
 };
 int conv3x3_pair_tile(int C, int Ws);   // output positions per workgroup, 0 = geometry not supported
 hipError_t launch_conv3x3_pair(const PairConvParams& p, int C, hipStream_t s);
+// THREE consecutive layers of equal dilation (a, a + 1, a + 2) in one kernel, 16-bit tensors only (conv3x3_tile.hip): res15's runs
+// (4,5,6) (7,8,9) (10,11,12) and every run of hey_snips.  Two shapes, by the parity of a (reference model/resnet.py:46-55):
+//   a even:  x_a = relu(conv_a(in)) + res  ->  y = relu(conv_{a+1}(x_a))  ->  out = relu(conv_{a+2}(y)) + x_a
+//            (in = y_{a-1}; res = x_{a-2} comes from memory in the layout it was written in; x_a never leaves the CU)
+//   a odd:   y = relu(conv_a(in))  ->  x_{a+1} = relu(conv_{a+1}(y)) + in  ->  out = relu(conv_{a+2}(x_{a+1}))
+//            (in = x_{a-1}; x_{a+1} is ALSO stored, to out2 in the input's own layout: it is the next even layer's residual)
+struct TripleConvParams {
+    const void* in;        // CL 16-bit tensor in layout(2^ld)
+    const void* res;       // a even: x_{a-2} in layout(2^ld_res) (cells through the table); a odd: nullptr
+    void* out;             // the third layer's output, written in layout(2^ld_out)
+    void* out2;            // a odd: x_{a+1}, written in layout(2^ld) (cell = flattened position); a even: nullptr
+    const unsigned short* apk[3];   // weights in the fragment order of the single-layer kernel
+    const float* border[3];         // (16, C padded to 8) border-bias tables, or nullptr
+    float inv_scale[3];             // 2^-S of the fp16 weights (1 for bf16)
+    int first_even;        // parity of a
+    int B, H, W, Cout;
+    int ld, ld_out;
+    int Hs, Ws, total;     // sub-map size and cells of the input layout (as TileConvParams)
+    int f16;               // operand / tensor type: fp16 (1) or bf16 (0)
+    RangeGate rg;
+    const int* postab;     // build_tile_conv_table(H, W, ld, ld_out, ld_res): the three layers share the input layout
+    int cpc_in, cpc_out, cpc_res;
+    int wrap_clips;        // set by the launcher: whole clips added to a (possibly negative) halo position before it is decoded
+    int debug;             // KWS_T3_DEBUG, timing experiments only (results wrong): 1 / 64 / 128 skip the first / second / third k-loop, 2 skip the staging loads, 4 skip the output stores
+};
+bool conv3x3_triple_supported(int C, int Ws, bool first_even);
+hipError_t launch_conv3x3_triple(const TripleConvParams& p, int C, hipStream_t s);
 // First conv of the cnn-* models from an LDS image of the clip (conv_in1.hip): Cin == 1, kw == 8, no padding, fused MaxPool
 struct In1ConvParams {
     const float* feat;     // (B, T, F) fp32 feature maps

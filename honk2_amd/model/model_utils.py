@@ -158,3 +158,6 @@ class BaseModel(ABC, nn.Module):
 
     def plan_name(self):
         return self.engine().plan_name()
+
+    def plan_detail(self):
+        return self.engine().plan_detail()

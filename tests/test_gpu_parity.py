@@ -575,6 +575,51 @@ def test_layer_pairs_in_one_kernel_are_bit_identical(torch_cuda, dtype, case, mo
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ["res15", "res26", "hey_snips", "short"])
+def test_layer_triples_in_one_kernel_are_bit_identical(torch_cuda, dtype, case, monkeypatch):
+    """16-bit tensors on the tiled plan: a run of THREE layers of one dilation runs in one kernel (conv3x3_triple_kernel; reference
+    model/resnet.py:20-26, 46-55) -- first layer even (residual from memory in its own layout, x_a kept in LDS as the third layer's
+    residual) or odd (residual = the staged input, x_{a+1} also stored for the next even layer).  Both intermediate maps are rounded
+    as the stores they replace: logits equal the pairs-and-singles form AND the one-kernel-per-layer form bit for bit.  res15 (runs
+    at dilations 2, 4, 8 by default, 1 too wide for the LDS), res26 (one run of 24 layers: pairs stay), hey_snips (dilations to 128, partial sub-maps, 901 frames), and a 37-frame, 12-layer
+    model whose maps are smaller than a workgroup tile; batches that span several workgroups and a chunk boundary."""
+    torch = torch_cuda
+    from oracle import weights
+    if case == "res15":
+        cfg, n, t = {"n_feature_maps": 45, "n_layers": 13, "use_dilation": True, "n_labels": 12}, 1100, 101
+    elif case == "res26":
+        cfg, n, t = {"n_feature_maps": 45, "n_layers": 24, "use_dilation": False, "pool": [2, 2], "n_labels": 12}, 300, 101
+    elif case == "hey_snips":
+        cfg, n, t = {"n_feature_maps": 45, "n_layers": 24, "use_dilation": True, "n_labels": 2}, 9, 901
+    else:
+        cfg, n, t = {"n_feature_maps": 45, "n_layers": 12, "use_dilation": True, "n_labels": 12}, 3, 37
+    sd = weights.make_state_dict("ResNet", cfg, seed=11)
+    x = torch.from_numpy(weights.make_features(n, seed=12, time=t)).cuda()
+    outs, plans = {}, {}
+    for tag, pair, triple in (("triples", "1", "1"), ("any_three", "1", "2"), ("pairs", "1", "0"), ("singles", "0", "0")):
+        monkeypatch.setenv("KWS_T3_PAIR", pair)
+        monkeypatch.setenv("KWS_T3_TRIPLE", triple)
+        m = _build(torch, "ResNet", dict(cfg, dtype=dtype), sd)
+        outs[tag] = m(x)
+        assert m.plan_name() == "resnet_tiled"
+        plans[tag] = m.plan_detail()
+    # what ran: the default takes runs of exactly three (res15: dilations 2, 4, 8; dilation 1's halo rows do not fit the LDS), "any_three" every
+    # three consecutive layers of one dilation
+    assert "triple" not in plans["pairs"] and "pair(" in plans["pairs"] and "pair" not in plans["singles"], plans
+    if case == "res15":
+        assert plans["triples"] == "conv0 pair(1,2) conv(3) triple(4,5,6) triple(7,8,9) triple(10,11,12) conv(13) mean+linear", plans
+    elif case == "res26":
+        assert "triple" not in plans["triples"], plans      # (a run of 24; with 20-cell rows an odd-first run's three maps exceed the LDS, so "any_three" stays on pairs too)
+    elif case == "hey_snips":
+        assert plans["triples"].count("triple") == 7 and "pair(1,2) conv(3)" in plans["triples"], plans
+    else:
+        assert plans["triples"].count("triple") >= 3, plans
+    assert torch.isfinite(outs["singles"]).all()
+    for tag in ("triples", "any_three", "pairs"):
+        assert torch.equal(outs[tag], outs["singles"]), (tag, float((outs[tag] - outs["singles"]).abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_layer_pairs_on_odd_shapes(torch_cuda, dtype, monkeypatch):
     """The pair kernel where no shipped config puts it: maps smaller than one workgroup tile (a batch of one 23-frame clip), a map whose
     flattened positions end inside a tile, a pooled map, dilations that reach past the map, 19 and 45 channels.  Bit-identical to the
