@@ -547,6 +547,9 @@ void build_tile_conv_table(int H, int W, int ld_in, int ld_out, int ld_res, std:
 #ifndef PAIR_APF
 #define PAIR_APF 3   // k-steps of weight-fragment look-ahead in the pair kernel (A/B knob)
 #endif
+#ifndef PAIR_BPF
+#define PAIR_BPF 1   // position tiles of B-fragment look-ahead in the pair / triple kernels (A/B knob)
+#endif
 template <int MT, bool F16>
 __device__ __forceinline__ void pair_first_frags(const __amdgpu_buffer_rsrc_t ars, int avoff, u32x4 (&a)[MT]) {
 #pragma unroll
@@ -570,13 +573,16 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int2_* ktab, c
     // Weight fragments are requested PAIR_APF k-steps ahead: a k-step is only JT x MT MFMAs (144 - 240 clocks), far less than the L2 round
     // trip the fragments take (two layers' weights do not stay in the CU's L1), and with one step of look-ahead every step waited for it.
     constexpr int APF = PAIR_APF;
-    u32x4 a[APF + 1][MT], bb[2];
+    constexpr int BPF = PAIR_BPF < JT ? PAIR_BPF : JT;      // B fragments are requested BPF position tiles ahead (ring of BPF + 1 buffers)
+    constexpr int TOTAL = STEPS * JT;
+    u32x4 a[APF + 1][MT], bb[BPF + 1];
     int2_ e_c = ktab[0];
 #pragma unroll
     for (int m = 0; m < MT; ++m) a[0][m] = a_first[m];   // k-step 0's fragments: requested by the caller ahead of its barrier
 #pragma unroll
     for (int u = 1; u < APF; ++u) load_a(a[u], u < STEPS ? u : STEPS - 1);
-    bb[0] = t3_lds_read16(b_addr(0, e_c));
+#pragma unroll
+    for (int u = 0; u < BPF; ++u) bb[u] = t3_lds_read16(b_addr(u, e_c));
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
         int2_ e_n = e_c;
@@ -586,14 +592,16 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int2_* ktab, c
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             const int t = s * JT + j;
-            if (j + 1 < JT) bb[(t + 1) & 1] = t3_lds_read16(b_addr(j + 1, e_c));
-            else if (s + 1 < STEPS) bb[(t + 1) & 1] = t3_lds_read16(b_addr(0, e_n));
+            if (t + BPF < TOTAL) {
+                const int jn = (j + BPF) % JT;
+                bb[(t + BPF) % (BPF + 1)] = t3_lds_read16(b_addr(jn, j + BPF < JT ? e_c : e_n));
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 if (s == 0) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (F16) TMFH(a[s % (APF + 1)][m], bb[t & 1], acc[j][m]);
-                else TMF(a[s % (APF + 1)][m], bb[t & 1], acc[j][m]);
+                if (F16) TMFH(a[s % (APF + 1)][m], bb[t % (BPF + 1)], acc[j][m]);
+                else TMF(a[s % (APF + 1)][m], bb[t % (BPF + 1)], acc[j][m]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

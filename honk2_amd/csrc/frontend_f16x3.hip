@@ -47,6 +47,9 @@ constexpr int XS = 164;                                        // LDS words per 
 #ifndef FE16_ORDER
 #define FE16_ORDER 0
 #endif
+#ifndef FE16_ISSUE    // where the next unit's sample loads are requested: 0 in one go behind the power tile, 1 in three parts through the mel stage
+#define FE16_ISSUE 1
+#endif
 constexpr int NTT = FE16_NT;                                   // 16-frame tiles per unit
 constexpr int FRM = 16 * NTT;                                  // frames per unit
 constexpr int WG_PER_CU = NTT <= 4 ? 3 : 2;
@@ -60,13 +63,16 @@ static_assert(PS % 4 == 2 && PS >= FRM, "rows of lane groups 0 and 1 must start 
 constexpr int IMG_WORDS = X_WORDS > FE_ROWS * PS ? X_WORDS : FE_ROWS * PS;   // the power tile replaces the (dead) sample image
 constexpr int MEL_SLOTS = (NTT + 3) / 4;                       // frame tiles per wave in the mel stage: tiles w, w + 4, ...
 constexpr int CONST_WORDS = FE16_CONST_WORDS;
+constexpr int MELW_WORDS = (IMG_WORDS - FE_ROWS * PS) / 1024 * 1024;   // what the image region leaves behind the power tile, in whole passes of the workgroup
+constexpr int MELW_ITERS = MELW_WORDS / 1024;
+static_assert(MELW_ITERS >= 1, "no room for the mel table behind the power tile");
 }  // namespace
 
 __device__ __forceinline__ int fx_idx(int i) { return i + 4 * (i / 160); }
 
 // phase timestamps for tools/fe_phases.py: build with -DFE16_TIMING (they overwrite part of the feature rows)
 #ifdef FE16_TIMING
-#define FE16_TS_DECL unsigned long long ts[8];
+#define FE16_TS_DECL unsigned long long ts[13];
 #define FE16_TS(i) ts[i] = __builtin_readcyclecounter();
 #else
 #define FE16_TS_DECL
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
         else if (tid < 124) qe = qt + tid - 60;
         return (qe >= 0 && qe < len4 && (org + 4 * qe < 0 || org + 4 * qe + 3 >= n)) ? qe : -1;
     };
-    auto issue = [&](int unit, int tid) {
+    auto issue = [&](int unit, int tid, int it0 = 0, int it1 = iters, bool edges = true) {
         const int clip = unit / p.chunks;
         const int t0 = (unit - clip * p.chunks) * FRM;
         const int org = 160 * t0 - FE_NFFT / 2;
@@ -130,18 +136,21 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wav + cbase), 0, n * 4, 0x00020000);
 #pragma unroll
             for (int it = 0; it < iters; ++it) {
+                if (it < it0 || it >= it1) continue;
                 const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 4 * g0 + 3840 * it, 0, 0));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) raw[it][e] = v[e];
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) eraw[e][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * ex[e], 0, 0);
+            for (int e = 0; e < 4; ++e)
+                if (edges) eraw[e][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * ex[e], 0, 0);
         } else {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(p.pcm + cbase), 0, n * 2, 0x00020000);
             const __amdgpu_buffer_rsrc_t rz =       // only MODE 2 reads through it
                 __builtin_amdgcn_make_buffer_rsrc(MODE == 2 ? const_cast<float*>(p.noise + cbase) : nullptr, 0, MODE == 2 ? n * 4 : 0, 0x00020000);
 #pragma unroll
             for (int it = 0; it < iters; ++it) {
+                if (it < it0 || it >= it1) continue;
                 const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, 2 * g0 + 1920 * it, 0, 0));
                 raw[it][0] = v[0];
                 raw[it][1] = v[1];
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if (!edges) continue;
                 eraw[e][0] = (unsigned)(int)(short)__builtin_amdgcn_raw_buffer_load_b16(rs, 2 * ex[e], 0, 0);
                 if (MODE == 2) eraw[e][MODE == 2 ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b32(rz, 4 * ex[e], 0, 0);
             }
@@ -412,8 +422,25 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
                 sq[m][j][hh] = x * x;
             }
     }
+    FE16_TS(8)
     if (tid == 0) *next_unit = taken;
+    // the mel stage's A table (a multiple of 1 024 fp32 words) goes to the tail of the image region that the power tile leaves free, once the
+    // samples are dead: global_load_lds_dwordx4 (gfx950: memory -> LDS without passing through registers; lane i of a wave lands at base + 16 i),
+    // waited for in front of the barrier that precedes the mel stage, which reads it as ds_read_b32 (one bank per lane)
+    float* const melw_lds = lds + FE_ROWS * PS;
+    const int mel_words = ((p.mel_ns[0] + p.mel_ns[1] + p.mel_ns[2]) * 64 + 1023) & ~1023;   // (build_mel_gemm_table pads the table to that)
     __syncthreads();  // every wave is done with the sample image
+    FE16_TS(9)
+#if FE16_ISSUE == 2
+    const int nxt = *next_unit;
+    issue(min(nxt, nunits - 1), tid, 0, 4, false);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int i = 0; i < MELW_ITERS; ++i)
+        if (i * 1024 < mel_words)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.mel_a + i * 1024 + w * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(melw_lds + i * 1024 + w * 256), 16, 0, 0);
 
     // ---- power tile P[bin][frame] = Re^2 + Im^2 (row stride PS words).  Each cell has one Re and one Im owner: in
     //      the first half-phase the Re waves store their row tiles 0-1 and the Im waves their row tiles 2-3, in the
@@ -442,12 +469,42 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
 #else
     if (w < 2) { P_PHASE(0, *cell = v) } else { P_PHASE(2, *cell = v) }
     __syncthreads();
-    if (w < 2) { P_PHASE(2, *cell += v) } else { P_PHASE(0, *cell += v) }
+    FE16_TS(10)
+#if FE16_ISSUE == 2
+    issue(min(nxt, nunits - 1), tid, 4, 8, false);
+    __builtin_amdgcn_sched_barrier(0);
 #endif
+    {   // (r4) all 56 reads first, then the adds and stores: written as `*cell += v` the compiler kept every read behind the store in front of
+        // it -- 56 dependent LDS round trips, 5 - 6 k cycles of a unit's ~45 k
+        float got[2][NTT][4];
+#define P_READ(M0) { P_PHASE(M0, (got[mm][j][r] = *cell, (void)v)) }
+#define P_ADD(M0) { P_PHASE(M0, *cell = got[mm][j][r] + v) }
+        if (w < 2) {
+            P_READ(2)
+            P_ADD(2)
+        } else {
+            P_READ(0)
+            P_ADD(0)
+        }
+#undef P_READ
+#undef P_ADD
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the mel table has landed (requested two barriers ago)
 #undef P_PHASE
+    FE16_TS(11)
     __syncthreads();
+    FE16_TS(12)
+#if FE16_ISSUE != 2
     const int nxt = *next_unit;
+#else
+    issue(min(nxt, nunits - 1), tid, 8, 12, false);
+#endif
+#if FE16_ISSUE == 0
     issue(min(nxt, nunits - 1), tid);   // the accumulators are dead: prefetch the next unit's samples
+#elif FE16_ISSUE == 1                   // in three parts, one in front of each band tile of the mel stage
+    issue(min(nxt, nunits - 1), tid, 0, 7, false);
+#endif
 
     FE16_TS(4)
     // ---- mel + log + "DCT of length 1" (x2).  mel = W (bands x bins) . P (bins x frames) is a banded GEMM: band tile m (16
@@ -463,13 +520,24 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
 #pragma unroll
         for (int m = 0; m < 3; ++m) macc[q][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-        const float* atab = p.mel_a + lane;
+        // (r4) the A fragments come from the LDS copy of the table made above: read from global memory right in front of its own MFMAs, every
+        // group of four k-steps waited for an L2 round trip (9 groups x ~600 cycles of a unit's ~45 k)
+        const float* atab = melw_lds + lane;
         int pcol_off[MEL_SLOTS];
 #pragma unroll
         for (int q = 0; q < MEL_SLOTS; ++q) pcol_off[q] = 16 * min(w + 4 * q, NTT - 1) + pcol;   // a tile past the end re-reads the last one
         int step = 0;
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
+#if FE16_ISSUE == 1
+            if (m == 1) issue(min(nxt, nunits - 1), tid, 7, 13, false);
+            if (m == 2) issue(min(nxt, nunits - 1), tid, 13, iters, true);
+            __builtin_amdgcn_sched_barrier(0);
+#elif FE16_ISSUE == 2
+            if (m == 1) issue(min(nxt, nunits - 1), tid, 12, 16, false);
+            if (m == 2) issue(min(nxt, nunits - 1), tid, 16, iters, true);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             const int ns = p.mel_ns[m];
             const float* prow = lds + (4 * p.mel_fb[m] + g) * PS;
             for (int s0 = 0; s0 < ((FE16_ABLATE & 2) ? 4 : ns); s0 += 4, step += 4) {   // the host pads every tile to a multiple of four steps
@@ -552,6 +620,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
         unsigned long long* o = reinterpret_cast<unsigned long long*>(p.feat + ((size_t)clip * p.T + t0) * p.n_mels + 40 * (1 + w * 10));
         for (int i = 0; i < 8; ++i) o[i] = ts[i];
         o[8] = t8;
+        for (int i = 8; i < 13; ++i) o[i + 1] = ts[i];
     }
 #endif
     unit = nxt;
@@ -580,8 +649,8 @@ bool build_mel_gemm_table(const std::vector<float>& wts, const std::vector<int>&
         if (fb[m] < 0) return false;
         total += ns[m];
     }
-    if (total > FE16_MAX_STEPS) return false;
-    tab.assign((size_t)std::max(total, 1) * 64, 0.f);
+    if (total > FE16_MAX_STEPS || total * 64 > MELW_WORDS) return false;     // (the kernel keeps the table in LDS behind its power tile)
+    tab.assign(((size_t)std::max(total, 1) * 64 + 1023) / 1024 * 1024, 0.f);   // whole passes of the workgroup's copy loop
     int step = 0;
     for (int m = 0; m < 3; ++m)
         for (int s = 0; s < ns[m]; ++s, ++step)

@@ -868,6 +868,54 @@ def test_graph_replays_back_to_back_without_synchronisation(torch_cuda):
     assert torch.equal(model.forward_wav(srcs[0]), wants[0])      # and the eager path finds the queues as it left them
 
 
+def test_hundred_back_to_back_replays_at_the_shard_size(torch_cuda):
+    """The round-3 observation at its own scale, once: 100 replays of the captured wav -> logits graph of an 8 192-clip shard, launched
+    back to back with no host synchronisation.  Then each replay took 0.14 ms instead of 1.7 (most workgroups found the work queue
+    already drained) and the run ended in a memory fault.  Now a replay holds two kernel nodes whose queues re-arm themselves: the
+    replays must serialise (time per replay close to the eager call's, not a twelfth of it), the last one must leave the eager
+    result bit for bit, and the queue words must be back at zero for the eager call that follows."""
+    torch = torch_cuda
+    from oracle import weights
+    tag, name, cfg, sd, feats, z = load_golden_model("model_resnet__res8.npz")
+    model = _build(torch, name, cfg, sd)
+    n, reps = 8192, 100
+    base = torch.from_numpy(weights.make_waveforms(1024, seed=77)).cuda()
+    wav = base.repeat(8, 1) * torch.linspace(0.5, 1.0, n, device="cuda")[:, None]      # 8 192 distinct clips
+    want = model.forward_wav(wav).clone()
+    assert model.plan_name() == "res8_fused"
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(10):
+        model.forward_wav(wav)
+    ev[1].record()
+    torch.cuda.synchronize()
+    eager_ms = ev[0].elapsed_time(ev[1]) / 10
+    static_in = wav.clone()
+    out = torch.empty((n, cfg["n_labels"]), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        model.forward_wav(static_in, out=out)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            model.forward_wav(static_in, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    out.zero_()
+    ev[2].record()
+    for _ in range(reps):
+        graph.replay()
+    ev[3].record()
+    torch.cuda.synchronize()
+    replay_ms = ev[2].elapsed_time(ev[3]) / reps
+    assert torch.equal(out, want), float((out - want).abs().max())
+    assert replay_ms > 0.6 * eager_ms, (replay_ms, eager_ms)        # every replay did all of its work, one after the other
+    assert torch.equal(model.forward_wav(wav), want)
+    print({"eager_ms": round(eager_ms, 3), "replay_ms": round(replay_ms, 3)})
+
+
 @pytest.mark.parametrize("fname", ["model_resnet__res8.npz", "model_cnn__cnn-tpool2.npz"])
 def test_plain_c_client_of_the_abi(torch_cuda, fname, tmp_path):
     """The drop-in boundary is a C ABI: tests/c_abi/kws_c_client.c (gcc, libkws_hip.so + the HIP runtime, no Python, no PyTorch; device
