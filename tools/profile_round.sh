@@ -1,5 +1,5 @@
 #!/bin/bash
-# Per-round profiles (run on the GPU box from the repo root: tools/profile_round.sh <tag> [round dir, default r03]): rocprofv3 kernel stats of the default bench command, PMC passes for
+# Per-round profiles (run on the GPU box from the repo root: tools/profile_round.sh <tag> [round dir, default r04]): rocprofv3 kernel stats of the default bench command, PMC passes for
 # its two kernels, and kernel stats + PMC of BASELINE configs[2] / [4] in their own dtype.  Summaries -> gpurun_out/prof_<tag>*; tools/summarize_prof.py <dir> <tag> profiles/<round> turns them into the committed files
 tag=${1:-v9}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1

@@ -10,7 +10,7 @@ import os
 import sys
 
 
-def main(src, tag, dst="profiles/r03"):
+def main(src, tag, dst="profiles/r04"):
     os.makedirs(dst, exist_ok=True)
     summary = {}
     for path in glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True):
