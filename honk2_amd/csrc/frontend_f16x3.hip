@@ -431,9 +431,9 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     const int mel_words = ((p.mel_ns[0] + p.mel_ns[1] + p.mel_ns[2]) * 64 + 1023) & ~1023;   // (build_mel_gemm_table pads the table to that)
     __syncthreads();  // every wave is done with the sample image
     FE16_TS(9)
-#if FE16_ISSUE == 2
+#if FE16_ISSUE >= 2
     const int nxt = *next_unit;
-    issue(min(nxt, nunits - 1), tid, 0, 4, false);
+    issue(min(nxt, nunits - 1), tid, 0, FE16_ISSUE == 2 ? 4 : 7, false);
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     if (w < 2) { P_PHASE(0, *cell = v) } else { P_PHASE(2, *cell = v) }
     __syncthreads();
     FE16_TS(10)
-#if FE16_ISSUE == 2
-    issue(min(nxt, nunits - 1), tid, 4, 8, false);
+#if FE16_ISSUE >= 2
+    issue(min(nxt, nunits - 1), tid, FE16_ISSUE == 2 ? 4 : 7, FE16_ISSUE == 2 ? 8 : 13, false);
     __builtin_amdgcn_sched_barrier(0);
 #endif
     {   // (r4) all 56 reads first, then the adds and stores: written as `*cell += v` the compiler kept every read behind the store in front of
@@ -495,10 +495,12 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     FE16_TS(11)
     __syncthreads();
     FE16_TS(12)
-#if FE16_ISSUE != 2
+#if FE16_ISSUE < 2
     const int nxt = *next_unit;
-#else
+#elif FE16_ISSUE == 2
     issue(min(nxt, nunits - 1), tid, 8, 12, false);
+#else
+    issue(min(nxt, nunits - 1), tid, 13, iters, true);
 #endif
 #if FE16_ISSUE == 0
     issue(min(nxt, nunits - 1), tid);   // the accumulators are dead: prefetch the next unit's samples

@@ -22,7 +22,7 @@
  *     library BORROWS them for the duration of the call and never frees them).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every compute call is
  *     asynchronous on that stream and performs no host synchronisation and no allocation, so a call
- *     sequence can be captured into a hipGraph (launches of one handle must still not overlap: INTEGRATION.md section 2) -- with two one-time exceptions, both on the FIRST compute
+ *     sequence can be captured into a hipGraph and replayed back to back without synchronisation (a captured call is kernel nodes only: the persistent kernels' work queues re-arm themselves) -- with two one-time exceptions, both on the FIRST compute
  *     call that needs them (so: run one un-captured warm-up call per clip length first): the re-packed
  *     parameters are uploaded when the first call after kws_load_weights finalises them, and the tiled
  *     ResNet plan (res15 / res26 / narrow models, res8 on clips that are not one second long) builds and
@@ -30,8 +30,9 @@
  *     buffers of their own; tables of earlier clip lengths are kept and never rewritten).
  *   - every function returns 0 (KWS_OK) or a negative KWS_E* code; kws_last_error() returns a
  *     thread-local human-readable message for the last failure on the calling thread.
- *   - a handle is bound to the HIP device that was current at kws_create and is not re-entrant
- *     (one in-flight call per handle); distinct handles are independent.
+ *   - a handle is bound to the HIP device that was current at kws_create and is not re-entrant: its calls share one workspace,
+ *     so they must be ordered on ONE stream (consecutive launches and graph replays there need nothing else), never run
+ *     concurrently on two; distinct handles are independent.
  *   - KWS_DTYPE_F32: results are fp32-accurate (fp32 accumulation everywhere).  Products are formed on the 16-bit matrix cores
  *     from split fp32 operands: three exact fp16 x fp16 terms of two-part fp16 splits (weights pre-scaled by a power of two per
  *     layer; error <= 3 * 2^-22 |ab|, measured as close to a float64 evaluation as an fp32 implementation), or --
