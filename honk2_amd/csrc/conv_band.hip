@@ -144,6 +144,9 @@ __device__ __forceinline__ void band_kloop(const __amdgpu_buffer_rsrc_t ars, con
     }
 }
 
+#ifndef BAND_STAGE_UNR
+#define BAND_STAGE_UNR 13
+#endif
 // MH: channel tiles per wave (the layer has up to 2 MH); TERMS: 3 (two-part operands, fp32-accurate) or 1 (fp16 tensor in, one part)
 template <int MH, int TERMS, int NT>
 __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
@@ -199,7 +202,10 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
         const int ncg = (nsrc + 15) / 16;
         const int nit = ncg * nqq;                               // wave-level items
         const int lc = lane & 15, lq = lane >> 4;
-        constexpr int UNR = 4;
+        // (r4) fp16 tensors: all of a wave's loads in flight together (13 items per wave for a 25-row band): with four per pass the staging was three to
+        // four memory round trips in a row, 5.3 of the workgroup's 31.7 us (tools/band_phases.py; cnn-trad-pool2 fp16 1.83 -> 1.79 ms).  The fp32 form
+        // splits what it loads and is no faster with more in flight (4.34 -> 4.43 ms): it keeps four.
+        constexpr int UNR = S16 ? BAND_STAGE_UNR : 4;
         for (int i0 = w; i0 < nit; i0 += UNR * 4) {
             f32x4 v[UNR];
             int dst[UNR];

@@ -474,18 +474,30 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     issue(min(nxt, nunits - 1), tid, FE16_ISSUE == 2 ? 4 : 7, FE16_ISSUE == 2 ? 8 : 13, false);
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    {   // (r4) all 56 reads first, then the adds and stores: written as `*cell += v` the compiler kept every read behind the store in front of
-        // it -- 56 dependent LDS round trips, 5 - 6 k cycles of a unit's ~45 k
-        float got[2][NTT][4];
-#define P_READ(M0) { P_PHASE(M0, (got[mm][j][r] = *cell, (void)v)) }
-#define P_ADD(M0) { P_PHASE(M0, *cell = got[mm][j][r] + v) }
+    {   // (r4) reads first, then the adds and stores, one row tile (28 cells) at a time: written as `*cell += v` the compiler kept every read behind the
+        // store in front of it -- 56 dependent LDS round trips, 5 - 6 k cycles of a unit's ~45 k
+        float got[NTT][4];
+#define P_TILE(M_, OP)                                                                         \
+    _Pragma("unroll") for (int j = 0; j < NTT; ++j)                                            \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+        float* cell = pt + (2 * (16 * (M_) + r)) * PS + 16 * j;                                \
+        const float v = sq[M_][j][r >> 1][r & 1];                                              \
+        OP;                                                                                    \
+    }
+#define P_READ(M0) { P_TILE(M0, (got[j][r] = *cell, (void)v)) }
+#define P_ADD(M0) { P_TILE(M0, *cell = got[j][r] + v) }
         if (w < 2) {
             P_READ(2)
             P_ADD(2)
+            P_READ(3)
+            P_ADD(3)
         } else {
             P_READ(0)
             P_ADD(0)
+            P_READ(1)
+            P_ADD(1)
         }
+#undef P_TILE
 #undef P_READ
 #undef P_ADD
     }

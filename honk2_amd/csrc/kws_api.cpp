@@ -642,6 +642,15 @@ int chunk_clips(size_t per_clip_elems, int B) {
     return (int)std::min<size_t>(cb, (size_t)std::max(B, 1));
 }
 
+// clips per launch of a cnn-* plan (KWS_CNN_CHUNK: experiments.  r4, cnn-trad-pool2 fp16 at B = 8 192: 512 clips 2.19 ms, 768 1.91, 1 024 1.79, 1 536 1.78 -- fewer, larger launches win
+// over whole rounds of workgroups; f32 likewise)
+int cnn_chunk(const kws_handle* h, int B) {
+    static const int env = std::getenv("KWS_CNN_CHUNK") ? std::atoi(std::getenv("KWS_CNN_CHUNK")) : 0;   // experiments
+    const size_t cap = env > 0 ? (size_t)env : 1024;
+    const size_t fit = ((size_t)1 << 28) / std::max<size_t>(h->cnn_max_elems, 1);     // every activation tensor under 1 GiB (chunk_clips)
+    return (int)std::max<size_t>(1, std::min<size_t>(std::min(fit, cap), (size_t)std::max(B, 1)));
+}
+
 // Linears (flat Cin == 1 "convs") over a chunk of clips launch only B/256 workgroups; split K so the chip is filled.
 int plan_ksplit(const ConvGeom& g, int nb, int steps) {
     if (!(g.kx_inner && g.ph == 0 && g.pw == 0)) return 1;
@@ -678,7 +687,7 @@ size_t act_bytes(const kws_handle* h, int B, int T) {
         return (s.pooled ? align256(full * cb * 4) : 0) + 2 * align256(small * cb * 4) + align256((size_t)8 * s.T * s.F * 4 + 4096);
     }
     if (h->plan == PLAN_CNN) {
-        const int cb = chunk_clips(h->cnn_max_elems, B);
+        const int cb = cnn_chunk(h, B);
         return 2 * align256(h->cnn_max_elems * cb * 4) + cnn_partial_bytes(h, cb) + align256((size_t)8 * h->d.time * h->d.freq * 4 + 4096);
     }
     return 0;
@@ -987,7 +996,7 @@ bool cnn_in1_plan(const kws_handle* h, int mode) {
 int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
     const kws_model_desc& d = h->d;
     if (T != d.time) return fail(KWS_EINVAL, "CNN was built for a different number of frames (config[\"time\"])");
-    const int cb = chunk_clips(h->cnn_max_elems, B);
+    const int cb = cnn_chunk(h, B);
     float* P = (float*)ws;
     float* Q = (float*)(ws + align256(h->cnn_max_elems * cb * 4));
     float* part = (float*)(ws + 2 * align256(h->cnn_max_elems * cb * 4));

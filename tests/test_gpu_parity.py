@@ -527,9 +527,9 @@ def test_layerwise_fp16_range_guard(torch_cuda, case):
                                                 "cnn-one-fpool3": "model_cnn__cnn-one-fpool3.npz"}[case])
         dtype = "fp16" if case.endswith("fp16") else "f32"
     sd = weights.make_state_dict(name, cfg, seed=5)
-    n_clean, n = 1024, 1100
+    n_clean, n = 1024, 1100                         # one chunk of every layer-wise plan
     feats = weights.make_features(n, seed=9)
-    feats[n_clean:] *= 40000.0                      # the second chunk's inputs are large: its activations leave fp16's range
+    feats[n_clean:] *= 40000.0                      # the later chunks' inputs are large: their activations leave fp16's range
     model = _build(torch, name, dict(cfg, dtype=dtype), sd)
     x = torch.from_numpy(feats).cuda()
     got = model(x).cpu().numpy()
