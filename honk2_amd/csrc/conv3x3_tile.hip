@@ -544,6 +544,28 @@ void build_tile_conv_table(int H, int W, int ld_in, int ld_out, int ld_res, std:
 // is read from the staged tile, not from memory.  Per pair: read 1.5 - 1.9 x + write 1 x instead of (1.26 + 1) + (1.26 + 1 + 1) tensor
 // passes, one launch instead of two; the halo row of y_i is computed twice (the matrix pipe has the room).
 // JTB: output position tiles per wave (TILE = 64 JTB positions); a wave takes up to 5 tiles of the intermediate map (<= 320 cells).
+// (r4) A 16-bit channels-last tile is the SAME bytes in memory and in LDS (consecutive cells, 96 B each): staging it is a flat copy, done by
+// global_load_lds_dwordx4 (gfx950: memory -> LDS without passing through registers; lane i of a wave-instruction lands at base + 16 i).  No register
+// round trip, no ds_write instructions, and the border tables' loads, the table entries and the first weight fragments share the tile's one memory
+// round trip instead of queueing behind it (tools/t3x_phases.py: staging was 5 - 7 us of a triple workgroup's 20 - 26).  Cells outside [0, total) are
+// clamped, not tested: they are never tapped.  The caller waits (s_waitcnt vmcnt(0)) in front of its barrier.
+#ifndef T3_DMA_STAGE
+#define T3_DMA_STAGE 1
+#endif
+template <int CELL>
+__device__ __forceinline__ void stage_cells_dma(const char* src, int first, int n_cells, int total, char* lds_dst, int w, int lane) {
+    constexpr int CH = CELL / 16;
+    const int nch = n_cells * CH;
+    for (int c0 = w * 64; c0 < nch; c0 += 256) {     // (wave-uniform: the LDS base goes through M0)
+        const int c = c0 + lane;
+        const int i = min(c / CH, n_cells - 1), qd = c - (c / CH) * CH;
+        const int q = min(max(first + i, 0), total - 1);
+        if (c < nch)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)q * CELL + qd * 16),
+                                             (__attribute__((address_space(3))) void*)(lds_dst + c0 * 16), 16, 0, 0);
+    }
+}
+
 #ifndef PAIR_APF
 #define PAIR_APF 3   // k-steps of weight-fragment look-ahead in the pair kernel (A/B knob)
 #endif
@@ -663,6 +685,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
     // ---- stage cells [P0 - 2 halo, P0 + TILE_P + 2 halo), tables
     {
         const int qd = tid % NQ, grp = tid / NQ;
+        if (T3_DMA_STAGE && !(p.debug & 2)) stage_cells_dma<CELL>(reinterpret_cast<const char*>(p.in), P0 - 2 * halo, n_in, p.total, lds + CELL, w, lane);
         if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
         if (tid < 4 * (STEPS + 2)) {
             const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
@@ -675,7 +698,9 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
             if (src) bv = *reinterpret_cast<const f32x4*>(src + 4 * r);
             *reinterpret_cast<f32x4*>(lds + border_off + 16 * t) = bv;
         }
-        if (grp < NGRP) {
+        if (T3_DMA_STAGE && !(p.debug & 2)) {
+            // (requested at the top of this block)
+        } else if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
             constexpr int UNR = 10;   // (TILE_P + 4 halo) / NGRP cells per pass: all of a thread's loads in flight together
             for (int i0 = grp; i0 < n_in; i0 += UNR * NGRP) {
@@ -697,6 +722,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
     const __amdgpu_buffer_rsrc_t ars_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk_b), 0, STEPS * MT * (F16 ? 2 : 3) * 1024, 0x00020000);
     u32x4 afirst[MT];
     pair_first_frags<MT, F16>(ars_a, lane * 16, afirst);   // in flight across the barrier
+    if (T3_DMA_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile has landed in LDS
     __syncthreads();
 
     const int2_* const ktab = reinterpret_cast<const int2_*>(lds + tab_off) + g;
@@ -889,6 +915,13 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
     t3_require_lds_base_zero(lds);
+#ifdef T3_TIMING   // 100 MHz wall-clock stamps of this workgroup's phases (tools/t3_phases.py --triple)
+    unsigned long long t3ts[12];
+#define T3X_TS(i) t3ts[i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define T3X_TS(i)
+#endif
+    T3X_TS(0)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -929,6 +962,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
     // ---- stage cells [P0 - 3 halo, P0 + TILE_P + 3 halo), tables
     {
         const int qd = tid % NQ, grp = tid / NQ;
+        if (T3_DMA_STAGE && !(p.debug & 2)) stage_cells_dma<CELL>(reinterpret_cast<const char*>(p.in), P0 - 3 * halo, n_in, p.total, lds + CELL, w, lane);
         if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
         if (tid < 4 * (STEPS + 2)) {
             const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
@@ -941,7 +975,9 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
             if (src) bv = *reinterpret_cast<const f32x4*>(src + 4 * r);
             *reinterpret_cast<f32x4*>(lds + border_off + 16 * t) = bv;
         }
-        if (grp < NGRP) {
+        if (T3_DMA_STAGE && !(p.debug & 2)) {
+            // (requested at the top of this block)
+        } else if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
             constexpr int UNR = 10;   // all of a thread's loads in flight together
             for (int i0 = grp; i0 < n_in; i0 += UNR * NGRP) {
@@ -987,7 +1023,10 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
             }
         }
     }
+    if (T3_DMA_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile has landed in LDS
+    T3X_TS(1)
     __syncthreads();
+    T3X_TS(2)
 
     const int2_* const ktab = reinterpret_cast<const int2_*>(lds + tab_off) + g;
     float amax = 0.f;
@@ -1004,6 +1043,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
                 for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         } else
             pair_kloop<NB, MT, F16, JT1>(lds, ktab, ars_a, lane * 16, afirst, lbase, tmask1, acc);
+        T3X_TS(3)
         pair_first_frags<MT, F16>(ars_b, lane * 16, afirst);   // the next layer's first fragments: in flight across the epilogue and the barrier
         {
             int q2[JT2], b2[JT2];
@@ -1032,7 +1072,9 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
             }
         }
     }
+    T3X_TS(4)
     __syncthreads();
+    T3X_TS(5)
     // ---------------------------------------------------------------- layer a + 1 on map 2's cells -> LDS (a odd: + the staged input, and -> out2)
     {
         int lbase[JT2], tmask[JT2];
@@ -1051,6 +1093,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
                 for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         } else
             pair_kloop<NB, MT, F16, JT2>(lds, ktab, ars_b, lane * 16, afirst, lbase, tmask, acc);
+        T3X_TS(6)
         pair_first_frags<MT, F16>(ars_c, lane * 16, afirst);
         {
             int q3[JTB];
@@ -1087,7 +1130,9 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
             }
         }
     }
+    T3X_TS(7)
     __syncthreads();
+    T3X_TS(8)
     // ---------------------------------------------------------------- layer a + 2 from map 2 (a even: + x_a from map 1) -> memory
     {
         int lbase[JTB], tmask[JTB];
@@ -1105,6 +1150,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
                 for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         } else
             pair_kloop<NB, MT, F16, JTB>(lds, ktab, ars_c, lane * 16, afirst, lbase, tmask, acc);
+        T3X_TS(9)
         char* const outp = reinterpret_cast<char*>(p.out);
 #pragma unroll
         for (int j = 0; j < JTB; ++j) {
@@ -1129,6 +1175,14 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
         }
     }
     range_note(p.rg, amax);
+#ifdef T3_TIMING
+    T3X_TS(10)
+    if (p.dbg_ts && lane == 0 && blockIdx.x < 8192) {     // 4 waves x 12 words per workgroup
+        unsigned long long* o = p.dbg_ts + ((size_t)blockIdx.x * 4 + w) * 12;
+        for (int i = 0; i < 11; ++i) o[i] = t3ts[i];
+        o[11] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    }
+#endif
 }
 
 // LDS bytes of the triple kernel for sub-maps Ws cells wide and TILE output positions per workgroup

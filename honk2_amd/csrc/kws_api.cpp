@@ -801,7 +801,26 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                     tp3.cpc_in = pt3->cpc[0]; tp3.cpc_out = pt3->cpc[1]; tp3.cpc_res = pt3->cpc[2];
                     static const int triple_dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
                     tp3.debug = triple_dbg;
+                    // KWS_T3_TIMING=<file> (timing builds only): phase stamps of the run that STARTS at layer KWS_T3_TIMING_LAYER, first chunk
+                    static const char* t3x_file = std::getenv("KWS_T3_TIMING");
+                    static const int t3x_layer = std::getenv("KWS_T3_TIMING_LAYER") ? std::atoi(std::getenv("KWS_T3_TIMING_LAYER")) : 2;
+                    static DevMem t3x_buf;
+                    const bool t3x_this = t3x_file && i == t3x_layer && b0 == 0 && !rg.gated;
+                    if (t3x_this) {
+                        std::vector<unsigned long long> z((size_t)8192 * 4 * 12, 0ull);
+                        if ((rc = t3x_buf.upload(z.data(), z.size() * 8))) return rc;
+                        tp3.dbg_ts = t3x_buf.as<unsigned long long>();
+                    }
                     HIP_TRY(launch_conv3x3_triple(tp3, C, s));
+                    if (t3x_this) {
+                        std::vector<unsigned long long> z((size_t)8192 * 4 * 12);
+                        HIP_TRY(hipStreamSynchronize(s));
+                        HIP_TRY(hipMemcpy(z.data(), t3x_buf.p, z.size() * 8, hipMemcpyDeviceToHost));
+                        if (FILE* f = std::fopen(t3x_file, "wb")) {
+                            std::fwrite(z.data(), 8, z.size(), f);
+                            std::fclose(f);
+                        }
+                    }
                     if (first_pass) note_layers("triple", i, 3);
                     // a even: x_{a+2} went to xn in the next run's layout; a odd: x_{a+1} went to xn in THIS run's layout (y_{a+2} is in Y)
                     std::swap(xc, xn);

@@ -398,6 +398,7 @@ struct TripleConvParams {
     const int* postab;     // build_tile_conv_table(H, W, ld, ld_out, ld_res): the three layers share the input layout
     int cpc_in, cpc_out, cpc_res;
     int wrap_clips;        // set by the launcher: whole clips added to a (possibly negative) halo position before it is decoded
+    unsigned long long* dbg_ts;   // KWS_T3_TIMING (with a -DT3_TIMING build): 12 stamps per wave for the first 8192 workgroups, or nullptr
     int debug;             // KWS_T3_DEBUG, timing experiments only (results wrong): 1 / 64 / 128 skip the first / second / third k-loop, 2 skip the staging loads, 4 skip the output stores
 };
 bool conv3x3_triple_supported(int C, int Ws, bool first_even);
