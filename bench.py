@@ -445,7 +445,13 @@ def literal_tone_record(torch, model, sd, device):
     return {"clip": "0.5 * sin(2 pi 1000 t), 16 000 samples, float32 (SURVEY.md 8d, literal)", "pairs": pairs,
             "oracle_f64_margin_top1_top2": float(top[-1] - top[-2]), "worst_pair_max_abs_dlogit": worst,
             "tol": 1e-3, "pass": bool(worst <= 1e-3 and all(v["argmax_equal"] for v in pairs.values())),
-            "bands_within_40dB": int(near.sum()), "bands_total": int(near.size)}
+            "bands_within_40dB": int(near.sum()), "bands_total": int(near.size),
+            # how to read it: a bin-centred tone leaves ~90 % of the mel bands pure rounding noise, so `pass` (every pair within 1e-3) fails for ANY
+            # two implementations, the oracle's own fp32-style and float64 variants included.  What can hold, and is asserted by the GPU test:
+            "all_pairs_argmax_equal": bool(all(v["argmax_equal"] for v in pairs.values())),
+            "all_pairs_agree_on_bands_within_40dB_of_peak": bool(all(v["max_abs_dfeature_within_40dB_of_peak"] < 1e-4 for v in pairs.values())),
+            "gpu_default_within_the_oracles_own_f32_f64_spread": bool(pairs["gpu_f16x3 vs oracle_f32"]["max_abs_dlogit"]
+                                                                      <= pairs["oracle_f32 vs oracle_f64"]["max_abs_dlogit"])}
 
 
 def parity_record(got, want, tol=1e-3):
