@@ -292,7 +292,14 @@ __global__ __launch_bounds__(256, 2) void conv_band_kernel(BandConvParams p) {
                 v[r] = co0 + r < p.Cout ? x : 0.f;
                 amax = fmaxf(amax, fabsf(v[r]));
             }
-            *reinterpret_cast<f32x4*>(outb + (size_t)opos[j] * p.Cpo + co0) = v;
+            if (p.out_f16) {
+                typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+                const u32x2 pk = {__builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[0], v[1]}, f16x2_)),
+                                  __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v[2], v[3]}, f16x2_))};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)b * p.Ho * p.Wo * p.Cpo + (size_t)opos[j] * p.Cpo + co0) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(outb + (size_t)opos[j] * p.Cpo + co0) = v;
+            }
         }
     }
     range_note(p.rg, amax);

@@ -149,6 +149,7 @@ struct kws_handle {
     size_t ws_bytes = 0;
     std::string plan_detail;               // tiled ResNet plan: what the last call launched per chunk (kws_plan_detail)
     int plan_detail_T = -1;
+    bool lin_in_f16 = true;                // cnn band plan, `fp16` dtype: fp16 cells between conv_1 and the first Linear (KWS_CNN_LIN_F16=0: fp32 cells, A/B and tests)
     int t3_triple = 1;                     // runs of three equal-dilation layers in one kernel (KWS_T3_TRIPLE=0: pairs + singles; 2: any three consecutive layers)
     bool t3_pair = true;                   // tiled plan, 16-bit tensors: consecutive layers of equal dilation in one kernel (KWS_T3_PAIR=0: off)
     DevMem r8_shift;                       // fused res8, kws_forward: per-clip power-of-two shifts of caller-provided features (feat_shift_kernel)
@@ -1060,6 +1061,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                     if ((rcb = launch_layer(h->cconv[0], g0, a0, s, terms))) return rcb;
                 }
                 const float* lin_in = Q;
+                bool lin_f16 = false;
                 if (band) {
                 const ConvGeom& g1 = h->cconv[1].g;
                 BandConvParams bp{};
@@ -1073,6 +1075,10 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                 bp.Wl = h->cnn_band.Wl; bp.PS = h->cnn_band.PS; bp.ntiles = h->cnn_band.ntiles;
                 bp.postab = h->cnn_band_tab.as<int>();
                 bp.terms = m_terms; bp.inv_scale = 1.0f / h->cconv[1].band_scale; bp.relu = 1; bp.rg = rg;
+                // (r4) single-term fp16 products: the Linear behind conv_1 rounds its input to fp16 anyway, so conv_1 stores that fp16 value (same bits out,
+                // half the bytes both ways) -- where the Linear takes its eight k-slots as one 16-byte load (rows of a multiple of eight cells' channels)
+                lin_f16 = m_f16 && m_terms == 1 && h->lin_in_f16 && ((long long)g1.Ho * g1.Wo * h->cnn_cp[1]) % 8 == 0;
+                bp.out_f16 = lin_f16 ? 1 : 0;
                 // KWS_BAND_TIMING=<file> (timing builds only): phase stamps of the first chunk's band kernel (tools/band_phases.py)
                 static const char* band_file = std::getenv("KWS_BAND_TIMING");
                 static DevMem band_buf;
@@ -1097,6 +1103,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                 }
                 ConvGeom gl = h->clin0_cl.g;
                 gl.B = nb;
+                gl.in_f16 = lin_f16 ? 1 : 0;
                 const bool last = h->clin.size() == 1;
                 float* dst = last ? logits + (size_t)b0 * d.n_labels : other(lin_in);
                 ConvArgs al{lin_in, dst, h->clin0_cl.apk.as<float>(), nullptr, h->clin[0].bias.as<float>(), nullptr, nullptr, rg};
@@ -1278,6 +1285,7 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
         else if (std::strcmp(lw, "nchw") == 0) h->lw_mode = LW_NCHW;
     }
     if (const char* tp = std::getenv("KWS_T3_TRIPLE")) h->t3_triple = std::atoi(tp);
+    if (const char* tp = std::getenv("KWS_CNN_LIN_F16")) h->lin_in_f16 = std::atoi(tp) != 0;
     if (const char* tp = std::getenv("KWS_T3_PAIR")) h->t3_pair = std::atoi(tp) != 0;   // A/B and tests: 0 = one kernel per layer
     int rc = setup_frontend(h.get());
     if (rc) return rc;

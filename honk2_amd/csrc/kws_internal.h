@@ -288,6 +288,8 @@ struct ConvGeom {
     int ksteps_split;      // k-steps per split
     int out_cl;            // conv_bf16x6_kernel only: 1 = write channels-last fp32 (B, npc, out_cp), 2 = the same as fp16 (for conv_band.hip);
     int out_cp;            // channels of a cell (Cout padded to 16, zeros in the padding); no split-K / accumulate / border then
+    int in_f16;            // conv_bf16x6_kernel, Linears over 16-byte aligned rows with single-term fp16 products only: the input holds fp16 values (conv_band.hip's
+                           // out_f16 cells) -- the operand the kernel would have rounded an fp32 input to, loaded as it is
 };
 struct ConvArgs {
     const float* in;       // (B, Cin, H, W)
@@ -437,6 +439,7 @@ struct BandConvParams {
     int terms;             // 3: two-part fp16 operands (fp32-accurate); 1: one part (`fp16` dtype, fp16 input tensor)
     float inv_scale;       // 2^-S of the weights
     int relu;
+    int out_f16;           // 1: `out` holds fp16 cells (round to nearest even) for a consumer that would round them to fp16 anyway (the first Linear with single-term products)
     RangeGate rg;
 };
 constexpr int conv_band_mh(int Cout) { return ((Cout + 15) / 16 + 1) / 2; }   // channel tiles per wave (two wave rows)

@@ -154,8 +154,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
     };
     setup_tiles(0);
 
+    // Linears (one kernel row over a flat input whose rows are 16-byte aligned): a block is fetched with two 16-byte loads.  Eight
+    // 4-byte loads of 16 clips 100 KB apart touched 64 cache lines per instruction: the first Linear of the cnn-* models (20 - 42 k
+    // inputs) ran at 1.6 TB/s, bound by the vector-memory path's line rate.
+    const bool vec8 = KX && gm.kh == 1 && gm.dw == 1 && gm.H == 1 && gm.ph == 0 && gm.pw == 0 && (gm.W & 3) == 0 && gm.sw == 1 && gm.Wo == 1;
+    const bool in16 = F16 && TERMS == 1 && vec8 && gm.in_f16 && (gm.W & 7) == 0;   // fp16 input cells (rows of whole 16-byte blocks)
     const __amdgpu_buffer_rsrc_t rin =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((size_t)gm.B * gm.Cin * hw * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((size_t)gm.B * gm.Cin * hw * (in16 ? 2 : 4)), 0x00020000);
     const int steps = gm.x_ksteps;
     const int s_begin = gm.ksplit > 1 ? (int)blockIdx.z * gm.ksteps_split : 0;
     const int s_end = gm.ksplit > 1 ? min(steps, s_begin + gm.ksteps_split) : steps;
@@ -167,10 +172,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
     const int nbr = gm.x_blocks_per_row;
     const int nblocks = gm.x_blocks;
     const int estride = (KX ? gm.dw : hw) * 4;   // byte stride between the 8 elements of a block
-    // Linears (one kernel row over a flat input whose rows are 16-byte aligned): a block is fetched with two 16-byte loads.  Eight
-    // 4-byte loads of 16 clips 100 KB apart touched 64 cache lines per instruction: the first Linear of the cnn-* models (20 - 42 k
-    // inputs) ran at 1.6 TB/s, bound by the vector-memory path's line rate.
-    const bool vec8 = KX && gm.kh == 1 && gm.dw == 1 && gm.H == 1 && gm.ph == 0 && gm.pw == 0 && (gm.W & 3) == 0 && gm.sw == 1 && gm.Wo == 1;
 
     f32x4 acc[MT][4];
 #pragma unroll
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
         if (KX) {   // unpadded, Cin == 1: row = ky, block = 8 kernel columns
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                voff[j] = (valid[j] && bok) ? (inb[j] + (iy0[j] + r * gm.dh) * gm.W + ix0[j] + 8 * c * gm.dw) * 4 : OOB;
+                voff[j] = (valid[j] && bok) ? (inb[j] + (iy0[j] + r * gm.dh) * gm.W + ix0[j] + 8 * c * gm.dw) * (in16 ? 2 : 4) : OOB;
         } else {    // row = tap (ky, kx), block = 8 input channels
             const int ky = r / gm.kw, kx = r - ky * gm.kw;
 #pragma unroll
@@ -205,7 +206,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
     {                                                                                                 \
         int voff_[4];                                                                                 \
         block_voff(S, voff_);                                                                         \
-        if (KX && vec8) {   /* Linear: the eight k-slots are 32 contiguous, 16-byte aligned bytes */  \
+        if (KX && vec8 && in16) {   /* fp16 cells: the eight k-slots are ONE 16-byte load, already the operand */ \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+                const u32x4 h_ = bload4(rin, voff_[j], 0);                                            \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) RAW[j][e] = __builtin_bit_cast(float, (unsigned)h_[e]); \
+            }                                                                                         \
+        } else if (KX && vec8) {   /* Linear: the eight k-slots are 32 contiguous, 16-byte aligned bytes */  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
                 const u32x4 lo_ = bload4(rin, voff_[j], 0), hi_ = bload4(rin, voff_[j], 16);          \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                       \
@@ -230,7 +236,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
             if (j >= ntile) continue;          /* windows with fewer members than tiles (uniform branch) */ \
             u32x4 bs_[3];                                                                             \
-            if (F16) split8_f16(RAW[j], bs_); else split8(RAW[j], bs_);                               \
+            if (in16) {                                                                               \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) bs_[0][e] = __builtin_bit_cast(unsigned, RAW[j][e]); \
+                bs_[1] = bs_[0];                                                                      \
+            } else if (F16) split8_f16(RAW[j], bs_); else split8(RAW[j], bs_);                        \
             _Pragma("unroll") for (int m = 0; m < MT; ++m) { XMF6(wa_[m], bs_, acc[m][j]) }           \
         }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \

@@ -1358,3 +1358,21 @@ def test_entry_point_reduces_over_rccl_with_a_one_rank_group(torch_cuda, tmp_pat
     assert a["info"]["backend"] is None and b["info"]["backend"] == "nccl"
     assert a["res"]["metric_Acc"] == b["res"]["metric_Acc"] and a["res"].get("metric_PerClassAcc") == b["res"].get("metric_PerClassAcc")
     assert abs(a["res"]["loss"] - b["res"]["loss"]) <= 1e-12 * max(1.0, abs(a["res"]["loss"]))
+
+
+def test_fp16_cells_between_conv_1_and_the_linear_change_no_bit(torch_cuda, monkeypatch):
+    """`fp16` dtype on the band plan (reference model/cnn.py:79-107 as a `.half()` model): the first Linear forms single-term fp16 products, i.e. it rounds
+    its input to fp16 itself -- so conv_1 may store exactly that fp16 value (half the bytes written and read).  Logits must equal the fp32-cell form bit
+    for bit, on the two-conv models that take the band plan, over a batch with a ragged second chunk."""
+    torch = torch_cuda
+    from oracle import weights
+    for fname in ("model_cnn__cnn-trad-pool2.npz", "model_cnn__cnn-tstride4.npz", "model_cnn__cnn-tpool2.npz"):
+        tag, name, cfg, sd, feats, z = load_golden_model(fname)
+        x = torch.from_numpy(weights.make_features(1100, seed=21)).cuda()
+        outs = {}
+        for knob in ("1", "0"):
+            monkeypatch.setenv("KWS_CNN_LIN_F16", knob)
+            m = _build(torch, name, dict(cfg, dtype="fp16"), sd)
+            outs[knob] = m(x)
+            assert m.plan_name() == "cnn_band", (fname, m.plan_name())
+        assert torch.isfinite(outs["1"]).all() and torch.equal(outs["1"], outs["0"]), (fname, float((outs["1"] - outs["0"]).abs().max()))
