@@ -1033,6 +1033,9 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             // the feature maps come from the caller: the first pass checks them like any stored activation -- conv_in1_kernel does that while it
             // stages the clip (NaN-aware); every other conv_0 gets range_check_kernel in front
             if (rg.flag && !rg.gated && !((band || cl1) && h->cnn_in1)) HIP_TRY(launch_range_check(cur, (long long)nb * d.time * d.freq, s, rg));
+            // single-conv models in the `fp16` dtype: conv_0's cells go straight into the first Linear, which rounds them to fp16 itself (see lin_f16 below)
+            const bool cl1_f16 = cl1 && !band && m_f16 && m_terms == 1 && h->lin_in_f16 &&
+                                 ((long long)(h->cconv[0].g.Ho / std::max(d.pool_kh[0], 1)) * (h->cconv[0].g.Wo / std::max(d.pool_kw[0], 1)) * h->cnn_cp[0]) % 8 == 0;
             if (band || cl1) {
                 // conv_0 (+ fused MaxPool) writes channels-last cells -- fp32, or fp16 with single-term products: from an LDS image
                 // of the clip (conv_in1.hip) where the layer fits it, else through the generic kernel's channels-last epilogue
@@ -1046,7 +1049,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                     ip.B = nb; ip.T = d.time; ip.F = d.freq; ip.Cout = g0.Cout; ip.Cp = h->cnn_cp[0]; ip.mtiles = g0.mtiles;
                     ip.kh = g0.kh; ip.sh = g0.sh; ip.sw = g0.sw; ip.ph = d.pool_kh[0]; ip.pw = d.pool_kw[0];
                     ip.Hq = g0.Ho / d.pool_kh[0]; ip.Wq = g0.Wo / d.pool_kw[0];
-                    ip.terms = m_terms; ip.inv_scale = 1.0f / h->cconv[0].x_scale; ip.relu = 1; ip.out_f16 = band && m_terms == 1; ip.rg = rg;
+                    ip.terms = m_terms; ip.inv_scale = 1.0f / h->cconv[0].x_scale; ip.relu = 1; ip.out_f16 = (band && m_terms == 1) || cl1_f16; ip.rg = rg;
                     HIP_TRY(launch_conv_in1(ip, s));
                 } else {
                     ConvGeom g0 = h->cconv[0].g;
@@ -1055,13 +1058,13 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                         g0.pool_h = d.pool_kh[0];
                         g0.pool_w = d.pool_kw[0];
                     }
-                    g0.out_cl = (band && m_terms == 1) ? 2 : 1;   // fp16 cells only for conv_band.hip; a Linear reads fp32
+                    g0.out_cl = ((band && m_terms == 1) || cl1_f16) ? 2 : 1;   // fp16 cells for conv_band.hip, or for a Linear that would round them to fp16 anyway
                     g0.out_cp = h->cnn_cp[0];
                     ConvArgs a0{cur, Q, h->cconv[0].apk.as<float>(), nullptr, h->cconv[0].bias.as<float>(), nullptr, nullptr, rg};
                     if ((rcb = launch_layer(h->cconv[0], g0, a0, s, terms))) return rcb;
                 }
                 const float* lin_in = Q;
-                bool lin_f16 = false;
+                bool lin_f16 = cl1_f16;
                 if (band) {
                 const ConvGeom& g1 = h->cconv[1].g;
                 BandConvParams bp{};

@@ -1366,7 +1366,8 @@ def test_fp16_cells_between_conv_1_and_the_linear_change_no_bit(torch_cuda, monk
     for bit, on the two-conv models that take the band plan, over a batch with a ragged second chunk."""
     torch = torch_cuda
     from oracle import weights
-    for fname in ("model_cnn__cnn-trad-pool2.npz", "model_cnn__cnn-tstride4.npz", "model_cnn__cnn-tpool2.npz"):
+    for fname, plan in (("model_cnn__cnn-trad-pool2.npz", "cnn_band"), ("model_cnn__cnn-tstride4.npz", "cnn_band"), ("model_cnn__cnn-tpool2.npz", "cnn_band"),
+                        ("model_cnn__cnn-one-fpool3.npz", "cnn_in1"), ("model_cnn__cnn-one-fstride4.npz", "cnn_in1")):   # (single-conv models: conv_0's cells feed the Linear)
         tag, name, cfg, sd, feats, z = load_golden_model(fname)
         x = torch.from_numpy(weights.make_features(1100, seed=21)).cuda()
         outs = {}
@@ -1374,5 +1375,5 @@ def test_fp16_cells_between_conv_1_and_the_linear_change_no_bit(torch_cuda, monk
             monkeypatch.setenv("KWS_CNN_LIN_F16", knob)
             m = _build(torch, name, dict(cfg, dtype="fp16"), sd)
             outs[knob] = m(x)
-            assert m.plan_name() == "cnn_band", (fname, m.plan_name())
+            assert m.plan_name() == plan, (fname, m.plan_name())
         assert torch.isfinite(outs["1"]).all() and torch.equal(outs["1"], outs["0"]), (fname, float((outs["1"] - outs["0"]).abs().max()))
