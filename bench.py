@@ -454,6 +454,45 @@ def literal_tone_record(torch, model, sd, device):
                                                                       <= pairs["oracle_f32 vs oracle_f64"]["max_abs_dlogit"])}
 
 
+def live_traffic(batch, kernel_substr="res8h_kernel", timeout_s=150):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this very script (two timed steps, nothing else) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- separate passes, KB units, x2 on the gfx950 fetch counter, as
+    MI355X_MICROARCH.md prescribes.  Children are started as ordinary child processes with python3 itself behind `--` (no exec from this process).
+    Returns a dict, or None where rocprofv3 is not installed; an error never takes the headline line down."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="kws_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--prewarm-ms", "0", "--batch", str(batch), "--no-cpu-baseline", "--no-secondary", "--no-shard",
+                   "--no-h2d", "--no-live-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KWS_FORCE_DIST", "KWS_BENCH_DUMP"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+            if r.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {ctr} exited with {r.returncode}: " + (r.stderr or r.stdout)[-300:]}
+            vals = [float(row["Counter_Value"]) for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+                    for row in csv.DictReader(open(path)) if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            if not vals:
+                return {"error": f"no {ctr} rows for {kernel_substr}"}
+            got[ctr] = (sum(vals) / len(vals), len(vals))
+        except Exception as exc:
+            return {"error": repr(exc)}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"bytes": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0, "FETCH_SIZE_KB_raw": got["FETCH_SIZE"][0],
+            "WRITE_SIZE_KB": got["WRITE_SIZE"][0], "launches_averaged": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]]}
+
+
 def parity_record(got, want, tol=1e-3):
     """GPU logits vs the oracle's on the same clips: the north-star bar (|diff| <= 1e-3, argmax equal).  With |diff| <= e on
     every logit the argmax can only differ where the oracle's own top-1 / top-2 margin is below 2 e, so a mismatch on a
@@ -484,6 +523,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] records (N = 1 only)")
     ap.add_argument("--no-shard", action="store_true", help="skip the 8 192-clip shard record (N = 1 only)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the pinned-host (PCIe-inclusive) record (N = 1 only)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not re-run two short rocprofv3 --pmc passes of this command for roofline.traffic (N = 1 only)")
     args = ap.parse_args()
 
     import torch
@@ -642,6 +682,18 @@ def main():
                     break
                 except Exception:
                     continue
+            # ... and measured in THIS run when rocprofv3 is here: two short child runs of this command under --pmc (after the timed region: they
+            # cannot disturb it).  The committed figure stays beside it, so a traffic regression shows as a disagreement inside one line.
+            if world == 1 and not args.no_live_traffic:
+                lt = live_traffic(args.batch)
+                if lt and "bytes" in lt:
+                    roofline["traffic_static_committed"] = roofline.get("traffic")
+                    roofline["traffic"] = lt["bytes"]
+                    roofline["traffic_live"] = lt
+                    roofline["traffic_source"] = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command, run as child processes "
+                                                  "after the timed region; committed summary beside it in traffic_static_committed: " + str(roofline.get("traffic_source")))
+                elif lt:
+                    roofline["traffic_live"] = lt
         out = {
             "metric": "1s-clips/sec end-to-end (wav->logits), res8 GSCv2", "value": clips_per_s, "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm": {"steps": prewarm_steps, "target_ms": args.prewarm_ms, "what": "untimed steps before the W warm-up steps: the clock governor settles over ~100 ms of load"},

@@ -658,7 +658,8 @@ int plan_ksplit(const ConvGeom& g, int nb, int steps) {
     const int mt = g.x_mt > 0 ? g.x_mt : g.MT;
     const long long wgs = (((long long)nb * g.Ho * g.Wo + 255) / 256) * ((g.mtiles + mt - 1) / mt);
     if (wgs >= 256 || steps < 64) return 1;
-    int ks = (int)std::min<long long>((1024 + wgs - 1) / wgs, steps / 16);
+    static const int min_steps = std::getenv("KWS_KSPLIT_MIN_STEPS") ? std::max(1, std::atoi(std::getenv("KWS_KSPLIT_MIN_STEPS"))) : 16;   // A/B knob: k-steps per split at least
+    int ks = (int)std::min<long long>((1024 + wgs - 1) / wgs, steps / min_steps);
     return std::max(1, std::min(ks, 256));
 }
 
