@@ -480,17 +480,24 @@ def live_traffic(batch, kernel_substr="res8h_kernel", timeout_s=150):
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
             if r.returncode != 0:
                 return {"error": f"rocprofv3 --pmc {ctr} exited with {r.returncode}: " + (r.stderr or r.stdout)[-300:]}
-            vals = [float(row["Counter_Value"]) for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
-                    for row in csv.DictReader(open(path)) if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            rows = [row for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True) for row in csv.DictReader(open(path))
+                    if row["Counter_Name"] == ctr]
+            vals = [float(row["Counter_Value"]) for row in rows if kernel_substr in row["Kernel_Name"]]
             if not vals:
                 return {"error": f"no {ctr} rows for {kernel_substr}"}
             got[ctr] = (sum(vals) / len(vals), len(vals))
+            fe = [float(row["Counter_Value"]) for row in rows if "frontend_f16_kernel" in row["Kernel_Name"]]
+            if fe:
+                got["fe_" + ctr] = sum(fe) / len(fe)
         except Exception as exc:
             return {"error": repr(exc)}
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return {"bytes": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0, "FETCH_SIZE_KB_raw": got["FETCH_SIZE"][0],
-            "WRITE_SIZE_KB": got["WRITE_SIZE"][0], "launches_averaged": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]]}
+    out = {"bytes": (2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024.0, "FETCH_SIZE_KB_raw": got["FETCH_SIZE"][0],
+           "WRITE_SIZE_KB": got["WRITE_SIZE"][0], "launches_averaged": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]]}
+    if "fe_FETCH_SIZE" in got and "fe_WRITE_SIZE" in got:     # the front-end kernel of the same runs (algorithmic: 64 000 B in + 16 160 B out per clip)
+        out["frontend_bytes"] = (2.0 * got["fe_FETCH_SIZE"] + got["fe_WRITE_SIZE"]) * 1024.0
+    return out
 
 
 def parity_record(got, want, tol=1e-3):
@@ -660,6 +667,7 @@ def main():
                     % (achieved / PEAK_F32_MFMA_TFLOPS))
         else:
             peak, kern, note = PEAK_F32_MFMA_TFLOPS, "res8_kernel (fused conv stack, fp32-input MFMA)", ""
+        frontend_traffic_live = None
         roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": None, "kernel_ms": k_ms, "launches": calls,
                     "flop_per_launch": F_ALG_MODEL * nloc, "note": note}
@@ -690,6 +698,8 @@ def main():
                     roofline["traffic_static_committed"] = roofline.get("traffic")
                     roofline["traffic"] = lt["bytes"]
                     roofline["traffic_live"] = lt
+                    if "frontend_bytes" in lt:
+                        frontend_traffic_live = lt["frontend_bytes"]
                     roofline["traffic_source"] = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of this command, run as child processes "
                                                   "after the timed region; committed summary beside it in traffic_static_committed: " + str(roofline.get("traffic_source")))
                 elif lt:
@@ -708,7 +718,7 @@ def main():
                             "overlap_fallback": overlap_fallback} if dist_on else None),
             "roofline": roofline,
             "frontend": {"kernel": "frontend_f16_kernel (reflect pad + Hann + 480-point DFT as three-term fp16 MFMA products + mel + log)",
-                         "kernel_ms": f_ms, "bound": "hbm", "bytes_per_clip": 80160,
+                         "kernel_ms": f_ms, "bound": "hbm", "bytes_per_clip": 80160, "traffic": frontend_traffic_live,
                          "hbm_GBps_algorithmic": (80160 * nloc / (f_ms * 1e-3) / 1e9) if f_ms > 0 else 0.0,
                          "frac_of_8TBps": (80160 * nloc / (f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if f_ms > 0 else 0.0},
             "b_alg": {"end_to_end": B_ALG, "as_built": B_BUILT,
