@@ -147,6 +147,12 @@ __device__ __forceinline__ void split4_f16(f32x4 x, u32x2 (&out)[2]) {
     }
 }  // namespace
 
+template <int CELL>
+__device__ __forceinline__ void stage_cells_dma(const char* src, int first, int n_cells, int total, char* lds_dst, int w, int lane);   // (defined with the pair kernel below)
+#ifndef T3_DMA_STAGE
+#define T3_DMA_STAGE 1
+#endif
+
 // NB: 8-channel blocks per cell (3: C <= 24, 6: C <= 48); MT: 16-channel output tiles (2 / 3).
 // F16 (the default, fp32-accurate): operands are two-part fp16 splits, three terms per product (res8_f16x3.hip; weights
 // arrive scaled by 2^S, the accumulator is scaled back in the epilogue's FMA); the LDS cell shrinks to 2 x NB*8 x 2 B, which
@@ -236,7 +242,9 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
             if (p.border) bv = *reinterpret_cast<const f32x4*>(p.border + 4 * tid);
             *reinterpret_cast<f32x4*>(lds + border_off + 16 * tid) = bv;
         }
-        if (grp < NGRP) {
+        if (S16 && T3_DMA_STAGE && !(p.debug & 2)) {     // 16-bit tensors: the tile is a flat copy, memory -> LDS without registers (stage_cells_dma)
+            stage_cells_dma<CELL>(reinterpret_cast<const char*>(p.in), P0 - Ws - 1, ncell, p.total, lds + CELL, w, lane);
+        } else if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
             for (int i0 = grp; i0 < ncell; i0 += UNR * NGRP) {
                 f32x4 v[UNR];
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
         }
     }
 
+    if (S16 && T3_DMA_STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile has landed in LDS
     T3_TS(2)
     __syncthreads();
     T3_TS(3)
