@@ -97,6 +97,12 @@ def test_frontend_known_answers():
     assert edges[peak] <= 1000.0 <= edges[peak + 2]
     out = frontend.compute_mfccs(tone)
     assert out.shape == (101, 40, 1) and out.dtype == np.float32
+    # SURVEY.md Appendix A's probe values (the survey's own evaluation of the same specification, NOT librosa output: the librosa part stays unpinned):
+    # band edges (item 6) and the output statistics of one second of uniform(-1, 1) noise (item 10: range ~ [-7.2, 4.9], mean ~ 0.66)
+    assert np.allclose(edges[:3], [20.0, 76.689, 133.378], atol=1e-3) and np.allclose(edges[-3:], [3558.61, 3772.86, 4000.0], atol=1e-2)
+    noise = np.random.default_rng(0).uniform(-1.0, 1.0, 16000).astype(np.float32)
+    f = frontend.compute_mfccs_batch(noise[None], "f64")[0]
+    assert abs(f.min() + 7.2) < 0.1 and abs(f.max() - 4.9) < 0.05 and abs(f.mean() - 0.66) < 0.01, (f.min(), f.max(), f.mean())
 
 
 def test_frontend_reflect_padding_matches_definition():
