@@ -6,7 +6,7 @@ name=$1; src=$2; flags=$3
 cd "$(dirname "$0")/../honk2_amd/csrc"
 make -s -j8 >/dev/null
 mkdir -p ../variants build/var_$name
-case "$src" in frontend_f16x3.hip) flags="$flags -fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers";; res8_f16x3.hip) flags="$flags -fno-slp-vectorize";; conv_band.hip) flags="$flags -mllvm -disable-post-ra";; esac   # the Makefile's per-file flag
+case "$src" in frontend_f16x3.hip) flags="$flags -fno-slp-vectorize -mllvm -amdgpu-use-amdgpu-trackers";; res8_f16x3.hip) flags="$flags -fno-slp-vectorize";; conv_band.hip) flags="$flags -mllvm -disable-post-ra";; conv3x3_tile.hip) flags="$flags -mllvm -amdgpu-sched-strategy=max-ilp";; esac   # the Makefile's per-file flag
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -fno-gpu-rdc $flags -x hip -c ${VARIANT_SRC:-$src} -o build/var_$name/$src.o
 objs=""
 for f in kws_api.cpp frontend.hip frontend_f16x3.hip res8_fused.hip res8_bf16x6.hip res8_f16x3.hip layerwise.hip layerwise_bf16x6.hip conv3x3_tile.hip conv_band.hip conv_in1.hip; do
