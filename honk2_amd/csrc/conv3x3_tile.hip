@@ -578,6 +578,14 @@ __device__ __forceinline__ void stage_cells_dma(const char* src, int first, int 
 #ifndef PAIR_APF
 #define PAIR_APF 3   // k-steps of weight-fragment look-ahead in the pair kernel (A/B knob)
 #endif
+#ifndef PAIR_NOFENCE     // A/B knob: 1 = no scheduling fences inside the pair / triple k-loops
+#define PAIR_NOFENCE 0
+#endif
+#if PAIR_NOFENCE
+#define PAIR_FENCE
+#else
+#define PAIR_FENCE __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifndef PAIR_BPF
 #define PAIR_BPF 1   // position tiles of B-fragment look-ahead in the pair / triple kernels (A/B knob)
 #endif
@@ -619,7 +627,7 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int2_* ktab, c
         int2_ e_n = e_c;
         if (s + 1 < STEPS) e_n = ktab[4 * (s + 1)];
         if (s + APF < STEPS) load_a(a[(s + APF) % (APF + 1)], s + APF);
-        __builtin_amdgcn_sched_barrier(0);
+        PAIR_FENCE
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             const int t = s * JT + j;
@@ -627,14 +635,14 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int2_* ktab, c
                 const int jn = (j + BPF) % JT;
                 bb[(t + BPF) % (BPF + 1)] = t3_lds_read16(b_addr(jn, j + BPF < JT ? e_c : e_n));
             }
-            __builtin_amdgcn_sched_barrier(0);
+            PAIR_FENCE
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 if (s == 0) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (F16) TMFH(a[s % (APF + 1)][m], bb[t % (BPF + 1)], acc[j][m]);
                 else TMF(a[s % (APF + 1)][m], bb[t % (BPF + 1)], acc[j][m]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            PAIR_FENCE
         }
         e_c = e_n;
     }
