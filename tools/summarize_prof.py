@@ -10,10 +10,21 @@ import os
 import sys
 
 
+def newest(src, pattern):
+    """gpurun MERGES what a call wrote into the local gpurun_out/: a directory that several calls profiled into holds one file set per call (named by
+    process id).  Only the newest file of each directory belongs to the run being summarised."""
+    by_dir = {}
+    for path in glob.glob(os.path.join(src, "**", pattern), recursive=True):
+        d = os.path.dirname(path)
+        if d not in by_dir or os.path.getmtime(path) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = path
+    return sorted(by_dir.values())
+
+
 def main(src, tag, dst="profiles/r04"):
     os.makedirs(dst, exist_ok=True)
     summary = {}
-    for path in glob.glob(os.path.join(src, "**", "*_kernel_stats.csv"), recursive=True):
+    for path in newest(src, "*_kernel_stats.csv"):
         rows = [r for r in csv.DictReader(open(path)) if "kws::" in r["Name"] or "nccl" in r["Name"].lower()]
         with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
@@ -23,7 +34,7 @@ def main(src, tag, dst="profiles/r04"):
             name = r["Name"].split("(")[0].replace("void ", "")
             summary.setdefault(name, {})["avg_ms"] = float(r["AverageNs"]) / 1e6
             summary[name]["calls"] = int(r["Calls"])
-    for path in glob.glob(os.path.join(src, "**", "*_counter_collection.csv"), recursive=True):
+    for path in newest(src, "*_counter_collection.csv"):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
         for r in csv.DictReader(open(path)):
