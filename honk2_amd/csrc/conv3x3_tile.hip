@@ -586,6 +586,9 @@ __device__ __forceinline__ void stage_cells_dma(const char* src, int first, int 
 #else
 #define PAIR_FENCE __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifndef PAIR_READ_SLOT   // A/B knob: where a tile's look-ahead fragment read sits (see pair_kloop)
+#define PAIR_READ_SLOT 0
+#endif
 #ifndef PAIR_BPF
 #define PAIR_BPF 1   // position tiles of B-fragment look-ahead in the pair / triple kernels (A/B knob)
 #endif
@@ -631,16 +634,28 @@ __device__ __forceinline__ void pair_kloop(const char* lds, const int2_* ktab, c
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             const int t = s * JT + j;
+#if PAIR_READ_SLOT == 0      // the next fragment's address + read in front of the tile's MFMAs
             if (t + BPF < TOTAL) {
                 const int jn = (j + BPF) % JT;
                 bb[(t + BPF) % (BPF + 1)] = t3_lds_read16(b_addr(jn, j + BPF < JT ? e_c : e_n));
             }
             PAIR_FENCE
+#endif
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 if (s == 0) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (F16) TMFH(a[s % (APF + 1)][m], bb[t % (BPF + 1)], acc[j][m]);
                 else TMF(a[s % (APF + 1)][m], bb[t % (BPF + 1)], acc[j][m]);
+#if PAIR_READ_SLOT == 1      // ... or behind the first one: their issue falls into that MFMA's shadow
+                if (m == 0) {
+                    PAIR_FENCE
+                    if (t + BPF < TOTAL) {
+                        const int jn = (j + BPF) % JT;
+                        bb[(t + BPF) % (BPF + 1)] = t3_lds_read16(b_addr(jn, j + BPF < JT ? e_c : e_n));
+                    }
+                    PAIR_FENCE
+                }
+#endif
             }
             PAIR_FENCE
         }
