@@ -47,6 +47,9 @@ constexpr int XS = 164;                                        // LDS words per 
 #ifndef FE16_ORDER
 #define FE16_ORDER 0
 #endif
+#ifndef FE16_ASPREAD  // 1: the k-loop's A-fragment requests spread over four tiles of a k-step (A/B knob)
+#define FE16_ASPREAD 1
+#endif
 #ifndef FE16_ISSUE    // where the next unit's sample loads are requested: 0 in one go behind the power tile, 1 in three parts through the mel stage
 #define FE16_ISSUE 1
 #endif
@@ -372,6 +375,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
                     a[m][0] = an[m][0];
                     a[m][1] = an[m][1];
                 }
+#if !FE16_ASPREAD
                 if (s + 1 < 4) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
@@ -379,7 +383,22 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
                         an[m][1] = tab[((s + 1) * 8 + 2 * m + 1) * 64];
                     }
                 }
+#endif
             }
+#if FE16_ASPREAD   // the next k-step's eight fragments requested over the first four tiles of this one (2 per tile), not in one burst
+#if FE16_ASPREAD == 1
+            if (s + 1 < 4 && j < 4) {
+                an[j][0] = tab[((s + 1) * 8 + 2 * j) * 64];
+                an[j][1] = tab[((s + 1) * 8 + 2 * j + 1) * 64];
+            }
+#else                // 2: over six tiles -- two fragments with each of the first two, one with each of the next four
+            if (s + 1 < 4 && j < 6) {
+                const int f0 = j < 2 ? 2 * j : j + 2, nf = j < 2 ? 2 : 1;
+#pragma unroll
+                for (int f = f0; f < f0 + nf; ++f) an[f >> 1][f & 1] = tab[((s + 1) * 8 + f) * 64];
+            }
+#endif
+#endif
             u32x4 bh_n = bh_c, bl_n = bl_c;
             if (idx + 1 < 4 * NTT) {
                 const int s1 = (idx + 1) / NTT, j1 = (idx + 1) - s1 * NTT;
