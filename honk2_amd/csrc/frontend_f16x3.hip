@@ -386,18 +386,10 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
 #endif
             }
 #if FE16_ASPREAD   // the next k-step's eight fragments requested over the first four tiles of this one (2 per tile), not in one burst
-#if FE16_ASPREAD == 1
             if (s + 1 < 4 && j < 4) {
                 an[j][0] = tab[((s + 1) * 8 + 2 * j) * 64];
                 an[j][1] = tab[((s + 1) * 8 + 2 * j + 1) * 64];
             }
-#else                // 2: over six tiles -- two fragments with each of the first two, one with each of the next four
-            if (s + 1 < 4 && j < 6) {
-                const int f0 = j < 2 ? 2 * j : j + 2, nf = j < 2 ? 2 : 1;
-#pragma unroll
-                for (int f = f0; f < f0 + nf; ++f) an[f >> 1][f & 1] = tab[((s + 1) * 8 + f) * 64];
-            }
-#endif
 #endif
             u32x4 bh_n = bh_c, bl_n = bl_c;
             if (idx + 1 < 4 * NTT) {
@@ -450,11 +442,6 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     const int mel_words = ((p.mel_ns[0] + p.mel_ns[1] + p.mel_ns[2]) * 64 + 1023) & ~1023;   // (build_mel_gemm_table pads the table to that)
     __syncthreads();  // every wave is done with the sample image
     FE16_TS(9)
-#if FE16_ISSUE >= 2
-    const int nxt = *next_unit;
-    issue(min(nxt, nunits - 1), tid, 0, FE16_ISSUE == 2 ? 4 : 7, false);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
     for (int i = 0; i < MELW_ITERS; ++i)
         if (i * 1024 < mel_words)
@@ -489,10 +476,6 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     if (w < 2) { P_PHASE(0, *cell = v) } else { P_PHASE(2, *cell = v) }
     __syncthreads();
     FE16_TS(10)
-#if FE16_ISSUE >= 2
-    issue(min(nxt, nunits - 1), tid, FE16_ISSUE == 2 ? 4 : 7, FE16_ISSUE == 2 ? 8 : 13, false);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     {   // (r4) reads first, then the adds and stores, one row tile (28 cells) at a time: written as `*cell += v` the compiler kept every read behind the
         // store in front of it -- 56 dependent LDS round trips, 5 - 6 k cycles of a unit's ~45 k
         float got[NTT][4];
@@ -526,13 +509,7 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     FE16_TS(11)
     __syncthreads();
     FE16_TS(12)
-#if FE16_ISSUE < 2
     const int nxt = *next_unit;
-#elif FE16_ISSUE == 2
-    issue(min(nxt, nunits - 1), tid, 8, 12, false);
-#else
-    issue(min(nxt, nunits - 1), tid, 13, iters, true);
-#endif
 #if FE16_ISSUE == 0
     issue(min(nxt, nunits - 1), tid);   // the accumulators are dead: prefetch the next unit's samples
 #elif FE16_ISSUE == 1                   // in three parts, one in front of each band tile of the mel stage
@@ -565,10 +542,6 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
 #if FE16_ISSUE == 1
             if (m == 1) issue(min(nxt, nunits - 1), tid, 7, 13, false);
             if (m == 2) issue(min(nxt, nunits - 1), tid, 13, iters, true);
-            __builtin_amdgcn_sched_barrier(0);
-#elif FE16_ISSUE == 2
-            if (m == 1) issue(min(nxt, nunits - 1), tid, 12, 16, false);
-            if (m == 2) issue(min(nxt, nunits - 1), tid, 16, iters, true);
             __builtin_amdgcn_sched_barrier(0);
 #endif
             const int ns = p.mel_ns[m];
