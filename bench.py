@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: 1-s clips/sec end-to-end (wav -> logits), res8, GSCv2 shapes, on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: this process starts the N ranks itself, as fresh children)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                (the same ranks, started by the caller)
 
 A step = one pass of the hot path (kws_forward_wav: MFCC front end + res8) over the GLOBAL batch of synthetic
 16 kHz one-second clips (default 65 536, BASELINE.json configs[3] / the north-star target batch), sharded
@@ -519,6 +519,22 @@ def parity_record(got, want, tol=1e-3):
             "pass": ok}
 
 
+def rccl_version(torch):
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def load_launcher():
+    """honk2_amd/launch.py loaded BY PATH: importing the package would import torch, and the launching process stays torch-free."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_kws_launch", os.path.join(ROOT, "honk2_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -531,17 +547,25 @@ def main():
     ap.add_argument("--no-shard", action="store_true", help="skip the 8 192-clip shard record (N = 1 only)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the pinned-host (PCIe-inclusive) record (N = 1 only)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not re-run two short rocprofv3 --pmc passes of this command for roofline.traffic (N = 1 only)")
+    ap.add_argument("--allow-fallback", action="store_true", help="N > 1: if the side-stream all-gather is refused, gather on the compute stream instead of failing the run")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus {args.gpus}: need at least one GPU")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: this process becomes the launcher.  It has not imported torch, let alone touched the GPU; the N
+        # ranks are FRESH children (never an exec from a process that has initialised HIP) and rank 0's JSON line reaches stdout through
+        # the inherited descriptor.  The reference picks its GPU count from one integer inside one command the same way
+        # (run/test.py:69-70, utils/torch_utils.py:9-22).
+        raise SystemExit(load_launcher().launch_ranks(args.gpus, script=os.path.abspath(__file__), argv=sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
     from honk2_amd import dist_utils
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus and (world > 1 or args.gpus > 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
     # KWS_BENCH_BACKEND / KWS_BENCH_ONE_DEVICE are rehearsal knobs only (several ranks on one GPU over gloo, to exercise
     # the N > 1 code path on a single-GPU box); the real multi-GPU run uses RCCL with one GPU per rank.
     # KWS_FORCE_DIST=1 (under torchrun, one rank): the N > 1 code path -- process group, side-stream all-gather, barrier, all-reduce --
@@ -549,7 +573,9 @@ def main():
     backend = os.environ.get("KWS_BENCH_BACKEND", "nccl")
     rank, world = dist_utils.init_from_env(backend)
     dist_on = dist_utils.active()
-    local = 0 if os.environ.get("KWS_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+    local = dist_utils.local_device_index()
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local} but this node shows {torch.cuda.device_count()} GPU(s) -- --gpus {args.gpus} needs one GPU per rank")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -582,8 +608,10 @@ def main():
                 dist.all_gather_into_tensor(gbufs[1], lbufs[1])
             torch.cuda.synchronize()
         except Exception as exc:   # noqa: BLE001
+            if not args.allow_fallback:       # a run that silently measured a different collective pattern is not the run that was asked for
+                raise SystemExit(f"bench: rank {rank}: the side-stream all-gather failed ({exc!r}); pass --allow-fallback to gather on the compute stream instead")
             if rank == 0:
-                print(f"bench: overlapped all-gather unavailable ({exc!r}); gathering on the compute stream", file=sys.stderr)
+                print(f"bench: overlapped all-gather unavailable ({exc!r}); gathering on the compute stream (--allow-fallback)", file=sys.stderr)
             overlap, overlap_fallback = False, repr(exc)
             lbufs, gbufs, coll_stream = [logits], [gathered], None
     coll_done = [None, None]
@@ -647,6 +675,18 @@ def main():
     elapsed = float(tmax.item())
     if not bool(torch.isfinite(logits).all()):
         raise SystemExit("non-finite logits")
+    rank_devices, gather_ok = None, None
+    if dist_on:
+        # which device each rank computed on (did RCCL see N ranks on N GPUs: answerable from the line), and rank r's slice of the gathered
+        # logits against what rank r computed itself in the last step
+        mine = {"rank": rank, "local_device": local, "name": torch.cuda.get_device_name(local), "pci_bus_id": getattr(torch.cuda.get_device_properties(local), "pci_bus_id", None)}
+        rank_devices = [None] * dist.get_world_size()
+        dist.all_gather_object(rank_devices, mine)
+        gather_ok = bool(torch.equal(gathered[lo:hi], logits))
+        flag = torch.tensor([0 if gather_ok else 1], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise SystemExit(f"rank {rank}: the gathered logits differ from a rank's own shard")
 
     if rank == 0:
         clips_per_s = args.batch * args.steps / elapsed
@@ -713,9 +753,12 @@ def main():
                                    f"(BASELINE configs[3]), {nloc} clips/GPU, random-init weights",
                        "global_batch": args.batch, "clips_per_gpu": nloc, "n_samples": 16000,
                        "plan": model.plan_name(), "parallelism": f"dp{world} (clip sharding, logits all-gather" + (" on a side stream, overlapped with the next step" if overlap else "") + ")"},
-            "collective": ({"backend": dist.get_backend(), "world_size": world, "forced_one_rank_group": dist_utils.forced() and world == 1,
+            "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "forced_one_rank_group": dist_utils.forced() and world == 1,
+                            "rccl_version": rccl_version(torch) if backend == "nccl" else None,
+                            "clips_per_gpu": counts, "devices": rank_devices,
                             "op": "all_gather_into_tensor of the (B/N, 12) fp32 logits per step", "overlapped_on_side_stream": bool(overlap),
-                            "overlap_fallback": overlap_fallback} if dist_on else None),
+                            "overlap_fallback": overlap_fallback,
+                            "gathered_equals_local_shard_on_rank_0": gather_ok} if dist_on else None),
             "roofline": roofline,
             "frontend": {"kernel": "frontend_f16_kernel (reflect pad + Hann + 480-point DFT as three-term fp16 MFMA products + mel + log)",
                          "kernel_ms": f_ms, "bound": "hbm", "bytes_per_clip": 80160, "traffic": frontend_traffic_live,

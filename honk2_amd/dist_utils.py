@@ -23,10 +23,25 @@ def world():
     return 0, 1
 
 
+def _flag(name):
+    """An on/off environment knob: unset, empty and "0" are off."""
+    return os.environ.get(name, "0") not in ("", "0")
+
+
 def forced():
     """KWS_FORCE_DIST=1 under torchrun: take the distributed code path (process group, collectives, reductions) even at
     WORLD_SIZE 1 -- how a one-GPU box executes the RCCL calls the multi-GPU run makes (tests/test_gpu_parity.py)."""
-    return bool(os.environ.get("KWS_FORCE_DIST")) and "MASTER_ADDR" in os.environ
+    return _flag("KWS_FORCE_DIST") and "MASTER_ADDR" in os.environ
+
+
+def rehearsal_backend():
+    """KWS_BENCH_BACKEND=gloo: rehearse the N > 1 path with several ranks on a box with fewer GPUs (tests only; the real run is RCCL)."""
+    return os.environ.get("KWS_BENCH_BACKEND") or None
+
+
+def local_device_index():
+    """The GPU this rank computes on: LOCAL_RANK, or 0 for every rank under the rehearsal knob KWS_BENCH_ONE_DEVICE=1."""
+    return 0 if _flag("KWS_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
 
 
 def active():
@@ -40,9 +55,12 @@ def init_from_env(backend=None):
     if dist.is_initialized() or (n <= 1 and not forced()):
         return world()
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))   # one GPU per rank, before the communicator exists
+        backend = rehearsal_backend() or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        local = local_device_index()
+        if local >= torch.cuda.device_count():
+            raise RuntimeError(f"rank {os.environ.get('RANK', '0')}: local rank {local} but only {torch.cuda.device_count()} GPU(s) here (one GPU per rank)")
+        torch.cuda.set_device(local)                                     # one GPU per rank, before the communicator exists
     dist.init_process_group(backend=backend)
     return world()
 

@@ -8,8 +8,9 @@ three device syncs per batch) is replaced by the fused ``kws_eval_batch`` kernel
 the end; any other loss/metric falls back to calling them per batch exactly as the reference does.
 
 ``main`` repairs what cannot run in the reference as written (SURVEY.md finding F10): metrics are instantiated,
-``label_mapping`` is passed to ``evaluate``, ``evaluate_model_dir`` / ``best_dev_metric`` are optional.  Under
-``torchrun`` (WORLD_SIZE > 1) every rank evaluates a contiguous shard and logits are all-gathered over RCCL.
+``label_mapping`` is passed to ``evaluate``, ``evaluate_model_dir`` / ``best_dev_metric`` are optional.  With ``num_gpu`` > 1
+in the config (and that many GPUs present) the command starts one process per GPU itself (``cli`` -> ``launch.launch_ranks``; an
+explicit ``torchrun`` works too): every rank evaluates a contiguous shard of the batches and the counters are all-reduced over RCCL.
 """
 import argparse
 import os
@@ -154,7 +155,7 @@ def reduce_results(loss_sum, n_batches, metrics, label_mapping, device):
     global number of batches, which reproduces the single-process ``total_loss / len(data_loader)`` for any split."""
     import torch.distributed as dist
     n = len(label_mapping)
-    buf = torch.zeros(4 + 2 * n, dtype=torch.float64, device=device)
+    buf = torch.zeros(4 + 2 * n, dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     buf[0], buf[1] = loss_sum, n_batches
     for m in metrics.values():
         if isinstance(m, Acc):
@@ -178,7 +179,30 @@ def reduce_results(loss_sum, n_batches, metrics, label_mapping, device):
     return out
 
 
-if __name__ == "__main__":
+def ranks_for(config):
+    """How many processes `python -m honk2_amd.run.test` runs as: the config's ``num_gpu`` clamped to the GPUs present, exactly the
+    count the reference's ``prepare_device`` hands to ``DataParallel`` (``utils/torch_utils.py:9-22``, ``run/test.py:69-70``).
+    (``torch.cuda.device_count()`` does not initialise the GPU on ROCm.)"""
+    rehearse = os.environ.get("KWS_EVAL_RANKS")       # tests: N ranks on a box with fewer GPUs (with KWS_BENCH_BACKEND=gloo KWS_BENCH_ONE_DEVICE=1)
+    if rehearse:
+        return max(1, int(rehearse))
+    return max(1, min(int(config.get("num_gpu", 1)), torch.cuda.device_count()))
+
+
+def cli(argv=None):
     parser = argparse.ArgumentParser(description="MI355X-native honk2 evaluator")
     parser.add_argument("--config", default=None, required=True, type=str, help="path to a honk2 config file")
-    main(load_json(parser.parse_args().config))
+    args = parser.parse_args(argv)
+    config = load_json(args.config)
+    from .. import launch
+    n = ranks_for(config)
+    if n > 1 and not launch.under_launcher():
+        # one process per GPU: this process has made no HIP call yet and becomes the launcher of n fresh ranks of this very command
+        return launch.launch_ranks(n, module="honk2_amd.run.test", argv=["--config", args.config])
+    main(config)
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(cli())

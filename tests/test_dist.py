@@ -79,3 +79,56 @@ def test_two_rank_gather_and_reduce(tmp_path, total):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0.npy") and os.path.exists(tmp_path / "ok1.npy")
+
+
+def _write(path, text):
+    with open(path, "w") as f:
+        f.write(text)
+    return str(path)
+
+
+def test_one_command_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` / `python -m honk2_amd.run.test` with num_gpu > 1 become launchers (honk2_amd/launch.py): N fresh ranks
+    under torch.distributed.run on 127.0.0.1, exit code = the worst rank's.  Reference: one command, one integer (run/test.py:69-70)."""
+    from honk2_amd import launch
+    ok = _write(tmp_path / "ok.py",
+                "import os, sys\n"
+                f"sys.path.insert(0, {ROOT!r})\n"
+                "from honk2_amd import dist_utils\n"
+                "import torch, torch.distributed as dist\n"
+                "r, w = dist_utils.init_from_env('gloo')\n"
+                "t = torch.tensor([r + 1.0]); dist.all_reduce(t)\n"
+                "open(os.path.join(sys.argv[1], f'rank{r}.txt'), 'w').write(f'{w} {t.item()} {os.environ[\"MASTER_ADDR\"]}')\n"
+                "dist.destroy_process_group()\n")
+    assert launch.launch_ranks(2, script=ok, argv=[str(tmp_path)], timeout_s=300) == 0
+    assert open(tmp_path / "rank0.txt").read() == "2 3.0 127.0.0.1" and open(tmp_path / "rank1.txt").read() == "2 3.0 127.0.0.1"
+    bad = _write(tmp_path / "bad.py", "import os, sys\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
+    assert launch.launch_ranks(2, script=bad, timeout_s=300) != 0                      # one failing rank fails the command
+    with pytest.raises(ValueError):
+        launch.launch_ranks(2)
+    # bench.py's own front door: more than one GPU asked for and no rank environment -> it launches (no GPU here, so the ranks fail, loudly)
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in launch.RANK_ENV}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "64", "--prewarm-ms", "0"],
+                       env=dict(env, KWS_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "torch.distributed.run" not in r.stdout
+    assert "launch with torch.distributed.run" not in r.stderr                            # the round-4 refusal is gone
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]                 # and no line is printed for a run that did not happen
+
+
+def test_entry_point_rank_count_follows_num_gpu(monkeypatch):
+    """ranks_for: the config's num_gpu clamped to the GPUs present (reference prepare_device, utils/torch_utils.py:9-22)."""
+    from honk2_amd.run import test as entry
+    monkeypatch.delenv("KWS_EVAL_RANKS", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert entry.ranks_for({"num_gpu": 3}) == 3 and entry.ranks_for({"num_gpu": 16}) == 8 and entry.ranks_for({"num_gpu": 0}) == 1
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    assert entry.ranks_for({"num_gpu": 4}) == 1
+    monkeypatch.setenv("KWS_EVAL_RANKS", "2")
+    assert entry.ranks_for({"num_gpu": 1}) == 2
+    from honk2_amd import dist_utils
+    monkeypatch.setenv("KWS_FORCE_DIST", "0")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    assert not dist_utils.forced()                                                       # "0" is off
+    monkeypatch.setenv("KWS_FORCE_DIST", "1")
+    assert dist_utils.forced()

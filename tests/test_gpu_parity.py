@@ -1275,17 +1275,38 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(torch_cuda, tmp_path):
     import sys
     import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # `python bench.py --gpus 2` AS TYPED (no torchrun in front): the script starts its two ranks itself, as fresh children, and relays rank 0's line
     env = dict(os.environ, KWS_BENCH_BACKEND="gloo", KWS_BENCH_ONE_DEVICE="1", KWS_BENCH_DUMP=str(tmp_path / "n2.npy"))
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"),
                           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2048", "--prewarm-ms", "0"],
                          env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert two.returncode == 0, two.stderr[-2000:]
-    line2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    lines2 = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines2) == 1, lines2                                     # ONE JSON line, from rank 0
+    line2 = json.loads(lines2[-1])
     assert line2["n_gpus"] == 2 and line2["config"]["clips_per_gpu"] == 1024 and line2["config"]["global_batch"] == 2048
+    coll2 = line2["collective"]
+    assert coll2["world_size"] == 2 and coll2["clips_per_gpu"] == [1024, 1024] and coll2["backend"] == "gloo"
+    assert [d["rank"] for d in coll2["devices"]] == [0, 1] and coll2["gathered_equals_local_shard_on_rank_0"]
+    # more ranks than GPUs without the rehearsal knob: every rank but the first has no device -- the run must fail loudly, not shrink
+    env_bad = dict(env)
+    env_bad.pop("KWS_BENCH_ONE_DEVICE")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2048", "--prewarm-ms", "0"],
+                         env=env_bad, capture_output=True, text=True, timeout=600, cwd=root)
+    if torch_cuda.cuda.device_count() < 2:
+        assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+    # the explicit torchrun form the driver documents stays valid
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    tr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2048", "--prewarm-ms", "0"],
+                        env=dict(env, KWS_BENCH_DUMP=str(tmp_path / "n2t.npy")), capture_output=True, text=True, timeout=600, cwd=root)
+    assert tr.returncode == 0, tr.stderr[-2000:]
+    assert np.array_equal(np.load(tmp_path / "n2t.npy"), np.load(tmp_path / "n2.npy"))
     assert line2["steps"] == 2 and line2["warmup"] == 1 and line2["value"] > 0 and line2["scaling"] == "strong"
     assert "cpu_baseline" not in line2 and line2["roofline"]["launches"] == 2 and line2["prewarm"]["steps"] == 0
     env1 = dict(os.environ, KWS_BENCH_DUMP=str(tmp_path / "n1.npy"))
@@ -1322,7 +1343,7 @@ def test_bench_two_ranks_rehearsal_matches_one_rank(torch_cuda, tmp_path):
         assert rc.returncode == 0, rc.stderr[-2000:]
         liner = json.loads([ln for ln in rc.stdout.splitlines() if ln.startswith("{")][-1])
         coll = liner["collective"]
-        assert coll["backend"] == "nccl" and coll["world_size"] == 1 and coll["forced_one_rank_group"]
+        assert coll["backend"] == "nccl" and coll["world_size"] == 1 and coll["forced_one_rank_group"] and coll["rccl_version"]
         assert coll["overlapped_on_side_stream"] and coll["overlap_fallback"] is None, coll
         assert np.array_equal(np.load(tmp_path / "n1r.npy"), a)
 
@@ -1358,6 +1379,17 @@ def test_entry_point_reduces_over_rccl_with_a_one_rank_group(torch_cuda, tmp_pat
     assert a["info"]["backend"] is None and b["info"]["backend"] == "nccl"
     assert a["res"]["metric_Acc"] == b["res"]["metric_Acc"] and a["res"].get("metric_PerClassAcc") == b["res"].get("metric_PerClassAcc")
     assert abs(a["res"]["loss"] - b["res"]["loss"]) <= 1e-12 * max(1.0, abs(a["res"]["loss"]))
+    # `python -m honk2_amd.run.test --config X` AS TYPED with more than one rank wanted (num_gpu > 1 on a multi-GPU node; here the rehearsal
+    # knobs: two ranks on the one GPU over gloo): the command starts its ranks itself and rank 0 prints the single-process result
+    import ast
+    env2 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env2.update(KWS_EVAL_RANKS="2", KWS_BENCH_BACKEND="gloo", KWS_BENCH_ONE_DEVICE="1")
+    typed = subprocess.run([sys.executable, "-m", "honk2_amd.run.test", "--config", cfg], env=env2, capture_output=True, text=True, timeout=600, cwd=root)
+    assert typed.returncode == 0, typed.stderr[-2000:]
+    assert typed.stdout.count("Test results") == 1 and "(per rank, 2 ranks)" in typed.stdout
+    c = ast.literal_eval(typed.stdout.split("Test results", 1)[1].strip())
+    assert c["metric_Acc"] == a["res"]["metric_Acc"] and c.get("metric_PerClassAcc") == a["res"].get("metric_PerClassAcc")
+    assert abs(c["loss"] - a["res"]["loss"]) <= 1e-9 * max(1.0, abs(a["res"]["loss"]))
 
 
 def test_fp16_cells_between_conv_1_and_the_linear_change_no_bit(torch_cuda, monkeypatch):
