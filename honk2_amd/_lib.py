@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# KWS_LIB points experiments (A/B builds of one kernel) at another build of the same library; default = the in-tree build
+# KWS_LIB points experiments (A/B builds of one kernel, the EXPERIMENTS=1 build with its debug / timing switches) at another build of the
+# same library; default = the in-tree product build
+EXP_LIB_PATH = os.path.join(_HERE, "libkws_hip_exp.so")
 LIB_PATH = os.environ.get("KWS_LIB") or os.path.join(_HERE, "libkws_hip.so")
 
 KWS_MODEL_NONE, KWS_MODEL_RESNET, KWS_MODEL_CNN = 0, 1, 2
@@ -57,10 +59,17 @@ def load():
             f"honk2_amd: HIP extension {LIB_PATH} is missing. Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C honk2_amd/csrc`). "
             "There is no CPU fallback.")
+    _lib = bind(LIB_PATH)
+    return _lib
+
+
+def bind(path):
+    """dlopen one build of the library and declare the C signatures of include/kws.h on it (`load()` for the product; tests bind the
+    experiments build -- `make -C honk2_amd/csrc EXPERIMENTS=1` -- beside it)."""
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:
-        raise RuntimeError(f"honk2_amd: cannot load {LIB_PATH}: {e}") from e
+        raise RuntimeError(f"honk2_amd: cannot load {path}: {e}") from e
     vp, ci, sz = C.c_void_p, C.c_int, C.c_size_t
     lib.kws_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
     lib.kws_create.restype = ci
@@ -104,7 +113,6 @@ def load():
     lib.kws_last_error.restype = C.c_char_p
     lib.kws_abi_version.argtypes = []
     lib.kws_abi_version.restype = ci
-    _lib = lib
     return lib
 
 

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
     // Consecutive tiles share their halo cells: blocks that share an XCD (blockIdx mod 8) take one contiguous run of tiles, so a
     // halo re-read hits that XCD's L2 instead of going out to the fabric again (bijective for any grid size).
     int tile_id = (int)blockIdx.x;
-    if (!(p.debug & 32)) {
+    if (!(KWS_DBG(p.debug & 32))) {
         const int nwg = (int)gridDim.x, xcd = tile_id & 7, q8 = nwg >> 3, r8 = nwg & 7;
         tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile_id >> 3);
     }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
             if (p.border) bv = *reinterpret_cast<const f32x4*>(p.border + 4 * tid);
             *reinterpret_cast<f32x4*>(lds + border_off + 16 * tid) = bv;
         }
-        if (S16 && T3_DMA_STAGE && !(p.debug & 2)) {     // 16-bit tensors: the tile is a flat copy, memory -> LDS without registers (stage_cells_dma)
+        if (S16 && T3_DMA_STAGE && !(KWS_DBG(p.debug & 2))) {     // 16-bit tensors: the tile is a flat copy, memory -> LDS without registers (stage_cells_dma)
             stage_cells_dma<CELL>(reinterpret_cast<const char*>(p.in), P0 - Ws - 1, ncell, p.total, lds + CELL, w, lane);
         } else if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
                     // Cells outside the tensor or in the padding of a sub-map are never tapped (tmask above), so whatever
                     // is copied for them is irrelevant: the address is clamped instead of tested.
                     const int q = min(max(P0 - Ws - 1 + i0 + u * NGRP, 0), p.total - 1);
-                    v[u] = (p.debug & 2) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * GCELL + qd * 16);
+                    v[u] = (KWS_DBG(p.debug & 2)) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * GCELL + qd * 16);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
     f32x4 resv[S16 ? 1 : JT][S16 ? 1 : MT];
     u32x2 resh[S16 ? JT : 1][S16 ? MT : 1];   // 16-bit tensors: four values in two words
     const char* const resp = reinterpret_cast<const char*>(p.res);
-    if (resp && !(p.debug & 8)) {
+    if (resp && !(KWS_DBG(p.debug & 8))) {
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
             const size_t rcell = (size_t)rcl[j] * GCELL;
@@ -363,19 +363,19 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
     static_assert(JT % 2 == 1, "the fragment buffers swap roles every k-step");
 
     u32x4 a0[MT][NP], a1[MT][NP], bb0[NP], bb1[NP];
-    if (p.debug & 16) TLOADA(a1, 1)   // (timing experiment: the k-loop then re-uses the first two steps' weight fragments)
+    if (KWS_DBG(p.debug & 16)) TLOADA(a1, 1)   // (timing experiment: the k-loop then re-uses the first two steps' weight fragments)
     int2_ e_c = ktab[0];
     TLOADA(a0, 0)
     TLOADB(bb0, b_addr(0, e_c))
-    for (int s = (p.debug & 1) ? STEPS : 0; s < STEPS; s += 2) {
+    for (int s = (KWS_DBG(p.debug & 1)) ? STEPS : 0; s < STEPS; s += 2) {
         int2_ e_n = ktab[4 * (s + 1)];
-        if (s + 1 < STEPS && !(p.debug & 16)) TLOADA(a1, s + 1)
+        if (s + 1 < STEPS && !(KWS_DBG(p.debug & 16))) TLOADA(a1, s + 1)
         __builtin_amdgcn_sched_barrier(0);
         TSTEP(a0, bb0, bb1, e_n)
         if (s + 1 >= STEPS) break;
         e_c = e_n;
         e_n = ktab[4 * (s + 2)];
-        if (s + 2 < STEPS && !(p.debug & 16)) TLOADA(a0, s + 2)
+        if (s + 2 < STEPS && !(KWS_DBG(p.debug & 16))) TLOADA(a0, s + 2)
         __builtin_amdgcn_sched_barrier(0);
         TSTEP(a1, bb1, bb0, e_n)
         e_c = e_n;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? T3_S16_WGS : (F16 && NB <= 3) ? 3
                 v[r] = relu1(fmaf(acc[j][m][r], p.inv_scale, bb[r])) + rv[r];
                 amax = fmaxf(amax, fabsf(v[r]));
             }
-            if (p.debug & 4) continue;
+            if (KWS_DBG(p.debug & 4)) continue;
             if (!S16) *reinterpret_cast<f32x4*>(outp + ocell + co0 * 4) = v;
             else *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
         }
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
     // ---- stage cells [P0 - 2 halo, P0 + TILE_P + 2 halo), tables
     {
         const int qd = tid % NQ, grp = tid / NQ;
-        if (T3_DMA_STAGE && !(p.debug & 2)) stage_cells_dma<CELL>(reinterpret_cast<const char*>(p.in), P0 - 2 * halo, n_in, p.total, lds + CELL, w, lane);
+        if (T3_DMA_STAGE && !(KWS_DBG(p.debug & 2))) stage_cells_dma<CELL>(reinterpret_cast<const char*>(p.in), P0 - 2 * halo, n_in, p.total, lds + CELL, w, lane);
         if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
         if (tid < 4 * (STEPS + 2)) {
             const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
             if (src) bv = *reinterpret_cast<const f32x4*>(src + 4 * r);
             *reinterpret_cast<f32x4*>(lds + border_off + 16 * t) = bv;
         }
-        if (T3_DMA_STAGE && !(p.debug & 2)) {
+        if (T3_DMA_STAGE && !(KWS_DBG(p.debug & 2))) {
             // (requested at the top of this block)
         } else if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int q = min(max(P0 - 2 * halo + i0 + u * NGRP, 0), p.total - 1);   // (cells that are never tapped: clamped, not tested)
-                    v[u] = (p.debug & 2) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * CELL + qd * 16);
+                    v[u] = (KWS_DBG(p.debug & 2)) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * CELL + qd * 16);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
             tmask[j] = (lm < n_mid && Pm >= 0 && Pm < p.total) ? pea[j] : 0;   // outside: no live tap, never read by conv_b either
         }
         f32x4 acc[JTA][MT];
-        if (p.debug & 1) {
+        if (KWS_DBG(p.debug & 1)) {
 #pragma unroll
             for (int j = 0; j < JTA; ++j)
 #pragma unroll
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
             tmask[j] = P0 + local < p.total ? peb[j][0] : 0;
         }
         f32x4 acc[JTB][MT];
-        if (p.debug & 64) {
+        if (KWS_DBG(p.debug & 64)) {
 #pragma unroll
             for (int j = 0; j < JTB; ++j)
 #pragma unroll
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_pair_kernel(PairConvParams p
                     v[r] = relu1(fmaf(acc[j][m][r], p.inv_scale_b, bb[r])) + rv[r];
                     amax = fmaxf(amax, fabsf(v[r]));
                 }
-                if (!(p.debug & 4)) *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
+                if (!(KWS_DBG(p.debug & 4))) *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
             }
         }
     }
@@ -885,7 +885,7 @@ hipError_t launch_conv3x3_pair(const PairConvParams& p, int C, hipStream_t s) {
     if (p.total <= 0) return hipSuccess;
     const int tile = conv3x3_pair_tile(C, p.Ws);
     if (!tile || (long long)p.total + 384 + 4 * p.Ws + 4 >= (1 << 24) || (long long)p.total * 96 >= (1LL << 31)) return hipErrorInvalidValue;
-    static const int wgs3_env = std::getenv("KWS_T3_PAIR_WGS3") ? std::atoi(std::getenv("KWS_T3_PAIR_WGS3")) : 1;   // A/B knob
+    static const int wgs3_env = experiment_int("KWS_T3_PAIR_WGS3", 1);
     // three workgroups per CU on 192-position tiles when three images fit (53 KB each) and y_i's tile fits four tiles per wave
     if (wgs3_env && 192 + 2 * (p.Ws + 1) <= 256 && conv3x3_pair_lds_bytes(48, p.Ws, 192) <= 53 * 1024)
         return p.f16 ? launch_pair_k<true, 3, 3>(p, s) : launch_pair_k<false, 3, 3>(p, s);
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
     // ---- stage cells [P0 - 3 halo, P0 + TILE_P + 3 halo), tables
     {
         const int qd = tid % NQ, grp = tid / NQ;
-        if (T3_DMA_STAGE && !(p.debug & 2)) stage_cells_dma<CELL>(reinterpret_cast<const char*>(p.in), P0 - 3 * halo, n_in, p.total, lds + CELL, w, lane);
+        if (T3_DMA_STAGE && !(KWS_DBG(p.debug & 2))) stage_cells_dma<CELL>(reinterpret_cast<const char*>(p.in), P0 - 3 * halo, n_in, p.total, lds + CELL, w, lane);
         if (tid < CELL / 16) *reinterpret_cast<u32x4*>(lds + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
         if (tid < 4 * (STEPS + 2)) {
             const int bi = tid, tap = bi / NB, cblk = bi - tap * NB, ty = tap / 3, tx = tap - 3 * ty;
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
             if (src) bv = *reinterpret_cast<const f32x4*>(src + 4 * r);
             *reinterpret_cast<f32x4*>(lds + border_off + 16 * t) = bv;
         }
-        if (T3_DMA_STAGE && !(p.debug & 2)) {
+        if (T3_DMA_STAGE && !(KWS_DBG(p.debug & 2))) {
             // (requested at the top of this block)
         } else if (grp < NGRP) {
             const char* src = reinterpret_cast<const char*>(p.in);
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int q = min(max(P0 - 3 * halo + i0 + u * NGRP, 0), p.total - 1);   // (cells that are never tapped: clamped, not tested)
-                    v[u] = (p.debug & 2) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * CELL + qd * 16);
+                    v[u] = (KWS_DBG(p.debug & 2)) ? (f32x4){1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const f32x4*>(src + (size_t)q * CELL + qd * 16);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
 #pragma unroll
         for (int j = 0; j < JT1; ++j) lbase[j] = ((w * JT1 + j) * 16 + pcol + halo + 1) * CELL;   // its cell in the input tile (behind the zero cell)
         f32x4 acc[JT1][MT];
-        if (p.debug & 1) {
+        if (KWS_DBG(p.debug & 1)) {
 #pragma unroll
             for (int j = 0; j < JT1; ++j)
 #pragma unroll
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
             tmask[j] = (lm < n_m2 && Pm >= 0 && Pm < p.total) ? pe2[j] : 0;
         }
         f32x4 acc[JT2][MT];
-        if (p.debug & 64) {
+        if (KWS_DBG(p.debug & 64)) {
 #pragma unroll
             for (int j = 0; j < JT2; ++j)
 #pragma unroll
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
                 }
                 const u32x2 pk = cl_pack4<F16>(v);
                 *reinterpret_cast<u32x2*>(lds + mid2_off + lm * CELL + co0 * 2) = pk;
-                if (!EVEN && own && !(p.debug & 4)) *reinterpret_cast<u32x2*>(out2p + (size_t)(P0 - halo + lm) * CELL + co0 * 2) = pk;
+                if (!EVEN && own && !(KWS_DBG(p.debug & 4))) *reinterpret_cast<u32x2*>(out2p + (size_t)(P0 - halo + lm) * CELL + co0 * 2) = pk;
             }
         }
     }
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
             tmask[j] = P0 + local < p.total ? pe3m[j] : 0;
         }
         f32x4 acc[JTB][MT];
-        if (p.debug & 128) {
+        if (KWS_DBG(p.debug & 128)) {
 #pragma unroll
             for (int j = 0; j < JTB; ++j)
 #pragma unroll
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(256, WGS) void conv3x3_triple_kernel(TripleConvPara
                     v[r] = relu1(fmaf(acc[j][m][r], p.inv_scale[2], bb[r])) + rv[r];
                     amax = fmaxf(amax, fabsf(v[r]));
                 }
-                if (!(p.debug & 4)) *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
+                if (!(KWS_DBG(p.debug & 4))) *reinterpret_cast<u32x2*>(outp + ocell + co0 * 2) = cl_pack4<F16>(v);
             }
         }
     }
@@ -1226,7 +1226,7 @@ static size_t conv3x3_triple_lds_bytes(int Ws, int tile, bool even) {
 // configurations built: 0 = none; 1: TILE 192, 4 + 4 tiles per wave in the first two phases, three workgroups per CU; 2: TILE 256, 5 + 5, two;
 // 3: TILE 192, 4 + 4, two; 4: TILE 192, 5 + 4, two (halo rows up to 32 cells)
 static int conv3x3_triple_config(int Ws, bool even) {
-    static const int forced = std::getenv("KWS_T3_TRIPLE_CFG") ? std::atoi(std::getenv("KWS_T3_TRIPLE_CFG")) : 0;   // A/B knob
+    static const int forced = experiment_int("KWS_T3_TRIPLE_CFG", 0);
     const int halo = Ws + 1;
     auto fits = [&](int cfg) {
         switch (cfg) {

@@ -684,7 +684,7 @@ hipError_t launch_frontend_f16(const FrontendParams& p, int n_cu, hipStream_t s)
     }
     if (p.B <= 0) return hipSuccess;
     const long long units = (long long)p.B * p.chunks;
-    static const int wgs_env = std::getenv("KWS_FE_WGS_PER_CU") ? std::atoi(std::getenv("KWS_FE_WGS_PER_CU")) : 0;   // experiments
+    static const int wgs_env = experiment_int("KWS_FE_WGS_PER_CU", 0);
     const int wgs = wgs_env > 0 && wgs_env < WG_PER_CU ? wgs_env : WG_PER_CU;
     const dim3 grid((unsigned)std::min<long long>(units, (long long)wgs * n_cu));      // persistent
     if (p.wav) hipLaunchKernelGGL(frontend_f16_kernel<0>, grid, dim3(256), lds, s, p);

@@ -39,6 +39,18 @@ int fail_hip(hipError_t e, const char* what) {
 struct DevMem {
     void* p = nullptr;
     size_t bytes = 0;
+    DevMem() = default;
+    DevMem(const DevMem&) = delete;              // owns its block: never copied (a copy would free it twice)
+    DevMem& operator=(const DevMem&) = delete;
+    DevMem(DevMem&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevMem& operator=(DevMem&& o) noexcept {
+        if (this != &o) {
+            if (p) (void)hipFree(p);
+            p = o.p; bytes = o.bytes;
+            o.p = nullptr; o.bytes = 0;
+        }
+        return *this;
+    }
     ~DevMem() { if (p) (void)hipFree(p); }
     int upload(const void* src, size_t n) {
         if (bytes < n) {
@@ -51,13 +63,22 @@ struct DevMem {
         HIP_TRY(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
         return KWS_OK;
     }
-    int reserve(size_t n) {   // grow only; contents are not kept (hipFree waits for the device: nothing in flight still reads the old block)
+    // Grow-only scratch of a COMPUTE call (contents are not kept).  A block that was ever handed to a kernel may be baked into a hipGraph the
+    // caller captured -- a replay would write freed memory if it were released here -- so an outgrown block is PARKED (freed with the handle),
+    // never freed; and nothing is allocated while `s` is being captured (hipMalloc would invalidate the capture): that call fails with
+    // KWS_ENOWORKSPACE and asks for the un-captured warm-up call at this batch size that include/kws.h prescribes.
+    int reserve_parked(size_t n, std::vector<void*>& parked, hipStream_t s, const char* what) {
         if (bytes >= n) return KWS_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-        HIP_TRY(hipMalloc(&p, n));
-        bytes = n;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+            return fail(KWS_ENOWORKSPACE, std::string(what) + ": this batch size needs a larger internal buffer and the stream is being captured -- "
+                                          "make one un-captured warm-up call with this (or a larger) batch size first");
+        const size_t want = std::max(n, 2 * bytes);          // geometric: a batch-size sweep parks O(log B) blocks
+        void* np = nullptr;
+        HIP_TRY(hipMalloc(&np, want));
+        if (p) parked.push_back(p);
+        p = np;
+        bytes = want;
         return KWS_OK;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -153,6 +174,7 @@ struct kws_handle {
     int t3_triple = 1;                     // runs of three equal-dilation layers in one kernel (KWS_T3_TRIPLE=0: pairs + singles; 2: any three consecutive layers)
     bool t3_pair = true;                   // tiled plan, 16-bit tensors: consecutive layers of equal dilation in one kernel (KWS_T3_PAIR=0: off)
     DevMem r8_shift;                       // fused res8, kws_forward: per-clip power-of-two shifts of caller-provided features (feat_shift_kernel)
+    std::vector<void*> parked;             // outgrown r8_shift blocks: a captured graph may still name them, so they live as long as the handle
     DevMem range_flag;                     // device words: [0] fp16 range guard of the layer-wise plans (kws_internal.h), [16] /
                                            // [32] clip / unit counters of the fused res8 and front-end kernels
 
@@ -167,6 +189,7 @@ struct kws_handle {
 
     ~kws_handle() {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
+        for (void* q : parked) (void)hipFree(q);
     }
 };
 
@@ -631,7 +654,7 @@ int tiled_chunk(const kws_handle* h, const ResnetShape& s, int B) {
     const size_t cells = resnet_cl_cells(h, s);
     const int cb = chunk_clips(std::max((size_t)s.C * s.T * s.F, cells * pad8(s.C)), B);
     size_t cap = (((size_t)1 << 24) - 4096) / cells;
-    static const int env_cap = std::getenv("KWS_TILED_CHUNK") ? std::atoi(std::getenv("KWS_TILED_CHUNK")) : 0;   // experiments
+    static const int env_cap = experiment_int("KWS_TILED_CHUNK", 0);
     if (env_cap > 0) cap = std::min<size_t>(cap, env_cap);
     return (int)std::max<size_t>(1, std::min<size_t>(cb, cap));
 }
@@ -646,7 +669,7 @@ int chunk_clips(size_t per_clip_elems, int B) {
 // clips per launch of a cnn-* plan (KWS_CNN_CHUNK: experiments.  r4, cnn-trad-pool2 fp16 at B = 8 192: 512 clips 2.19 ms, 768 1.91, 1 024 1.79, 1 536 1.78 -- fewer, larger launches win
 // over whole rounds of workgroups; f32 likewise)
 int cnn_chunk(const kws_handle* h, int B) {
-    static const int env = std::getenv("KWS_CNN_CHUNK") ? std::atoi(std::getenv("KWS_CNN_CHUNK")) : 0;   // experiments
+    static const int env = experiment_int("KWS_CNN_CHUNK", 0);
     const size_t cap = env > 0 ? (size_t)env : 1024;
     const size_t fit = ((size_t)1 << 28) / std::max<size_t>(h->cnn_max_elems, 1);     // every activation tensor under 1 GiB (chunk_clips)
     return (int)std::max<size_t>(1, std::min<size_t>(std::min(fit, cap), (size_t)std::max(B, 1)));
@@ -658,7 +681,7 @@ int plan_ksplit(const ConvGeom& g, int nb, int steps) {
     const int mt = g.x_mt > 0 ? g.x_mt : g.MT;
     const long long wgs = (((long long)nb * g.Ho * g.Wo + 255) / 256) * ((g.mtiles + mt - 1) / mt);
     if (wgs >= 256 || steps < 64) return 1;
-    static const int min_steps = std::getenv("KWS_KSPLIT_MIN_STEPS") ? std::max(1, std::atoi(std::getenv("KWS_KSPLIT_MIN_STEPS"))) : 16;   // A/B knob: k-steps per split at least
+    static const int min_steps = std::max(1, experiment_int("KWS_KSPLIT_MIN_STEPS", 16));   // k-steps per split at least
     int ks = (int)std::min<long long>((1024 + wgs - 1) / wgs, steps / min_steps);
     return std::max(1, std::min(ks, 256));
 }
@@ -801,11 +824,11 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                     tp3.rg = rg;
                     tp3.postab = pt3->mem.as<int>();
                     tp3.cpc_in = pt3->cpc[0]; tp3.cpc_out = pt3->cpc[1]; tp3.cpc_res = pt3->cpc[2];
-                    static const int triple_dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
+                    static const int triple_dbg = experiment_int("KWS_T3_DEBUG", 0);
                     tp3.debug = triple_dbg;
                     // KWS_T3_TIMING=<file> (timing builds only): phase stamps of the run that STARTS at layer KWS_T3_TIMING_LAYER, first chunk
-                    static const char* t3x_file = std::getenv("KWS_T3_TIMING");
-                    static const int t3x_layer = std::getenv("KWS_T3_TIMING_LAYER") ? std::atoi(std::getenv("KWS_T3_TIMING_LAYER")) : 2;
+                    static const char* t3x_file = experiment_str("KWS_T3_TIMING");
+                    static const int t3x_layer = experiment_int("KWS_T3_TIMING_LAYER", 2);
                     static DevMem t3x_buf;
                     const bool t3x_this = t3x_file && i == t3x_layer && b0 == 0 && !rg.gated;
                     if (t3x_this) {
@@ -858,7 +881,7 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                     pp.rg = rg;
                     pp.postab = pt2->mem.as<int>();
                     pp.cpc_in = pt2->cpc[0]; pp.cpc_out = pt2->cpc[1];
-                    static const int pair_dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
+                    static const int pair_dbg = experiment_int("KWS_T3_DEBUG", 0);
                     pp.debug = pair_dbg;
                     HIP_TRY(launch_conv3x3_pair(pp, C, s));
                     if (first_pass) note_layers("pair", i, 2);
@@ -890,11 +913,11 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                 }
                 tp.postab = pt->mem.as<int>();
                 tp.cpc_in = pt->cpc[0]; tp.cpc_out = pt->cpc[1]; tp.cpc_res = pt->cpc[2];
-                static const int t3_dbg = std::getenv("KWS_T3_DEBUG") ? std::atoi(std::getenv("KWS_T3_DEBUG")) : 0;
+                static const int t3_dbg = experiment_int("KWS_T3_DEBUG", 0);
                 tp.debug = t3_dbg;
                 // KWS_T3_TIMING=<file> (timing builds only): phase stamps of layer KWS_T3_TIMING_LAYER (default 2) of the first chunk
-                static const char* t3_file = std::getenv("KWS_T3_TIMING");
-                static const int t3_layer = std::getenv("KWS_T3_TIMING_LAYER") ? std::atoi(std::getenv("KWS_T3_TIMING_LAYER")) : 2;
+                static const char* t3_file = experiment_str("KWS_T3_TIMING");
+                static const int t3_layer = experiment_int("KWS_T3_TIMING_LAYER", 2);
                 static DevMem t3_buf;
                 const bool t3_this = t3_file && i == t3_layer && b0 == 0 && !rg.gated;
                 if (t3_this) {
@@ -1084,7 +1107,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                 lin_f16 = m_f16 && m_terms == 1 && h->lin_in_f16 && ((long long)g1.Ho * g1.Wo * h->cnn_cp[1]) % 8 == 0;
                 bp.out_f16 = lin_f16 ? 1 : 0;
                 // KWS_BAND_TIMING=<file> (timing builds only): phase stamps of the first chunk's band kernel (tools/band_phases.py)
-                static const char* band_file = std::getenv("KWS_BAND_TIMING");
+                static const char* band_file = experiment_str("KWS_BAND_TIMING");
                 static DevMem band_buf;
                 const bool band_this = band_file && b0 == 0 && !rg.gated;
                 if (band_this) {
@@ -1162,7 +1185,7 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
     if ((rc = prof_mark(h, h->ev_model, s))) return rc;
     if (h->plan == PLAN_RESNET) {
         if (use_fused(h, T)) {
-            static const int dbg = std::getenv("KWS_R8_DEBUG") ? std::atoi(std::getenv("KWS_R8_DEBUG")) : 0;
+            static const int dbg = experiment_int("KWS_R8_DEBUG", 0);
             if (h->res8_impl == 0) {
                 h->last_plan = "res8_fused";
                 Res8hParams p{};
@@ -1177,20 +1200,21 @@ int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, cha
                 p.queue = h->range_flag.as<unsigned>() + 16;   // (word 0 of that block is the layer-wise range flag)
                 if (!own_feat) {   // caller-provided features: any finite fp32 value (reference model/resnet.py:39-41)
                     // B words of the handle's own (ABI version 2 promised that kws_forward needs no workspace on this plan): grown, with a
-                    // blocking allocation, the first time a larger batch arrives -- one more reason for the un-captured warm-up call
-                    if ((rc = h->r8_shift.reserve(align256((size_t)B * sizeof(int))))) return rc;
+                    // blocking allocation, the first time a larger batch arrives (include/kws.h: the third warm-up exception); the outgrown
+                    // block stays alive for graphs captured at the smaller size
+                    if ((rc = h->r8_shift.reserve_parked(align256((size_t)B * sizeof(int)), h->parked, s, "kws_forward (fused res8 plan)"))) return rc;
                     int* fsh = h->r8_shift.as<int>();
                     HIP_TRY(launch_feat_shift(feat, B, T * h->d.freq, fsh, s));
                     p.feat_shift = fsh;
                 }
-                static const int r8_wgs = std::getenv("KWS_R8_WGS_PER_CU") ? std::atoi(std::getenv("KWS_R8_WGS_PER_CU")) : 2;
+                static const int r8_wgs = experiment_int("KWS_R8_WGS_PER_CU", 2);
                 HIP_TRY(launch_res8h(p, std::min(B, r8_wgs * h->n_cu), s));
             } else if (h->res8_impl == 2) {
                 h->last_plan = "res8_fused_fp32mfma";
                 Res8Params p{feat, logits, h->r8_w0a.as<float>(), h->r8_apk.as<f32x4>(), h->r8_bn.as<float>(),
                              h->r8_zcells.as<int>(), h->out_w.as<float>(), h->out_b.as<float>(), B, T, h->d.freq,
                              h->d.n_labels, dbg};
-                static const int grid_env = std::getenv("KWS_R8_GRID") ? std::atoi(std::getenv("KWS_R8_GRID")) : 512;
+                static const int grid_env = experiment_int("KWS_R8_GRID", 512);
                 HIP_TRY(launch_res8(p, std::min(B, grid_env), s));
             } else {
                 h->last_plan = "res8_fused_bf16x6";
@@ -1264,10 +1288,12 @@ const char* kws_last_error(void) { return g_err.c_str(); }
 int kws_create(const kws_model_desc* desc, kws_handle** out) {
     return guarded<int>([&]() -> int {
     if (!desc || !out) return fail(KWS_EINVAL, "null argument");
-    if (const char* t = std::getenv("KWS_TEST_THROW")) {   // fault injection for tests/test_host.py: what the guard makes of an exception
+#ifdef KWS_EXPERIMENTS
+    if (const char* t = std::getenv("KWS_TEST_THROW")) {   // fault injection (experiments build only; tests/test_host.py loads that build for it): what the guard makes of an exception
         if (std::strcmp(t, "bad_alloc") == 0) throw std::bad_alloc();
         throw std::runtime_error(t);
     }
+#endif
     if (desc->struct_size != (int)sizeof(kws_model_desc)) return fail(KWS_EINVAL, "kws_model_desc size mismatch (ABI)");
     if (desc->dtype != KWS_DTYPE_F32 && desc->dtype != KWS_DTYPE_BF16X3 && desc->dtype != KWS_DTYPE_BF16 &&
         desc->dtype != KWS_DTYPE_F16)
@@ -1280,8 +1306,8 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
     h->d = *desc;
     HIP_TRY(hipGetDevice(&h->device));
     HIP_TRY(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
-    if (const char* nc = std::getenv("KWS_N_CU"))   // experiments with CU-masked streams: size the persistent grids for fewer CUs
-        if (std::atoi(nc) > 0 && std::atoi(nc) < h->n_cu) h->n_cu = std::atoi(nc);
+    if (const int nc = experiment_int("KWS_N_CU", 0))   // experiments with CU-masked streams: size the persistent grids for fewer CUs
+        if (nc > 0 && nc < h->n_cu) h->n_cu = nc;
     const char* fl = std::getenv("KWS_FORCE_LAYERWISE");
     h->force_layerwise = fl && fl[0] == '1';
     if (const char* lw = std::getenv("KWS_LAYERWISE_IMPL")) {

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <atomic>
 #include <cstring>
 #include <string>
@@ -11,7 +12,35 @@
 
 #include "../../include/kws.h"
 
+// Experiment switches -- the KWS_R8_DEBUG / KWS_T3_DEBUG ablation bits (results wrong by construction), the *_TIMING phase stamps (a host
+// synchronisation and a device-to-host copy inside a compute call), the grid / chunk sizing knobs and the fault-injection hook -- exist only
+// in a `make EXPERIMENTS=1` build (tools/ uses it).  The default build reads none of those environment variables: `experiment_int` /
+// `experiment_str` return their defaults and KWS_DBG(x) is the constant 0, so the branches behind it are compiled out of every kernel.
+#ifdef KWS_EXPERIMENTS
+#define KWS_DBG(x) ((x) != 0)
+#else
+#define KWS_DBG(x) false
+#endif
+
 namespace kws {
+
+inline int experiment_int(const char* name, int dflt) {
+#ifdef KWS_EXPERIMENTS
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+inline const char* experiment_str(const char* name) {
+#ifdef KWS_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // ---------------------------------------------------------------- host-side fp16 helpers (weight packing of the fp16 paths)
 // fp32 -> fp16 bits, round to nearest even; subnormals and overflow handled (weights are finite)
@@ -291,6 +320,17 @@ struct ConvGeom {
     int in_f16;            // conv_bf16x6_kernel, Linears over 16-byte aligned rows with single-term fp16 products only: the input holds fp16 values (conv_band.hip's
                            // out_f16 cells) -- the operand the kernel would have rounded an fp32 input to, loaded as it is
 };
+
+// conv_bf16x6_kernel reads its input as fp16 cells (ConvGeom::in_f16) only in this geometry -- a Linear over 16-byte aligned rows with
+// single-term fp16 products -- and otherwise as fp32: ONE predicate for the kernel, the launcher (which refuses in_f16 where it does not
+// hold: the kernel would silently read fp16 cells as fp32) and the host that sets the flag.
+__host__ __device__ inline bool conv_x_vec8(const ConvGeom& g) {
+    return g.kx_inner && g.kh == 1 && g.dw == 1 && g.H == 1 && g.ph == 0 && g.pw == 0 && (g.W & 3) == 0 && g.sw == 1 && g.Wo == 1;
+}
+__host__ __device__ inline bool conv_x_in16_ok(const ConvGeom& g) {
+    return g.x_f16 && g.x_terms == 1 && conv_x_vec8(g) && (g.W & 7) == 0;
+}
+
 struct ConvArgs {
     const float* in;       // (B, Cin, H, W)
     float* out;            // (B, Cout, Ho, Wo)

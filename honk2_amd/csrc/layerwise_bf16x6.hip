@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x6_kernel(ConvGeom gm, ConvAr
     // Linears (one kernel row over a flat input whose rows are 16-byte aligned): a block is fetched with two 16-byte loads.  Eight
     // 4-byte loads of 16 clips 100 KB apart touched 64 cache lines per instruction: the first Linear of the cnn-* models (20 - 42 k
     // inputs) ran at 1.6 TB/s, bound by the vector-memory path's line rate.
-    const bool vec8 = KX && gm.kh == 1 && gm.dw == 1 && gm.H == 1 && gm.ph == 0 && gm.pw == 0 && (gm.W & 3) == 0 && gm.sw == 1 && gm.Wo == 1;
-    const bool in16 = F16 && TERMS == 1 && vec8 && gm.in_f16 && (gm.W & 7) == 0;   // fp16 input cells (rows of whole 16-byte blocks)
+    const bool vec8 = KX && conv_x_vec8(gm);
+    const bool in16 = F16 && TERMS == 1 && vec8 && gm.in_f16 && (gm.W & 7) == 0;   // fp16 input cells (rows of whole 16-byte blocks): conv_x_in16_ok, checked by the launcher
     const __amdgpu_buffer_rsrc_t rin =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((size_t)gm.B * gm.Cin * hw * (in16 ? 2 : 4)), 0x00020000);
     const int steps = gm.x_ksteps;
@@ -428,6 +428,7 @@ hipError_t launch_conv_bf16x6(const ConvGeom& g, const ConvArgs& a, hipStream_t 
         return hipErrorInvalidValue;
     if (g.out_cl && (g.ksplit > 1 || g.accumulate || a.border || g.out_cp % 16 || g.out_cp < g.Cout || g.out_cp > g.mtiles * 16))
         return hipErrorInvalidValue;
+    if (g.in_f16 && !conv_x_in16_ok(g)) return hipErrorInvalidValue;   // the kernel would read the fp16 cells as fp32
     switch (g.x_mt) {
         case 1: return launch_x_mt<1>(g, a, s);
         case 2: return launch_x_mt<2>(g, a, s);

@@ -170,7 +170,7 @@ __device__ __forceinline__ void x_layer(const Res8xParams& p, const XCtx& c, int
         __builtin_amdgcn_sched_barrier(0);                                                                         \
         X_STEP(fa1, o1, o2)                                                                                        \
     }
-    if (!(p.debug & 2)) {
+    if (!(KWS_DBG(p.debug & 2))) {
         if (TERMS == 1) {   // not MFMA-bound: left to the unroller this variant only spills
 #pragma unroll 1
             for (int s = 0; s < KSTEPS; s += 2) X_PAIR(s)
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void res8x_kernel(Res8xParams p) {
             for (int j = 0; j < 5; ++j) {
                 const int ad0 = lb[j] + koff[0], ad1 = lb[j] + koff[1], ad2 = lb[j] + koff[2];
                 f32x4 s0 = zero, s1 = zero, s2 = zero;
-                if (!(p.debug & 1)) {
+                if (!(KWS_DBG(p.debug & 1))) {
 #pragma unroll
                     for (int wp = 0; wp < 6; ++wp) {
                         f32x4 cc[2][3];
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void res8x_kernel(Res8xParams p) {
             {
                 const int ad0 = lb[5] + koff[0], ad1 = lb[5] + koff[1], ad2 = lb[5] + koff[2];
                 f32x4 sx = zero;
-                if (!(p.debug & 1)) {
+                if (!(KWS_DBG(p.debug & 1))) {
 #pragma unroll
                     for (int oy = 0; oy < 4; ++oy)
 #pragma unroll

@@ -325,17 +325,17 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
     // (in place: a separate copy would keep both values alive across the loop)
     asm volatile("" : "+v"(c.dB), "+v"(c.dC), "+v"(c.dD), "+v"(c.es[0]), "+v"(c.es[1]), "+v"(c.es[2]), "+v"(avoff));
     const int dB = c.dB, dC = c.dC, dD = c.dD, es[3] = {c.es[0], c.es[1], c.es[2]};
-    if (!(p.debug & 2)) {
+    if (!(KWS_DBG(p.debug & 2))) {
         // B fragments are fetched R8H_BDEPTH position tiles ahead (2 ds_read_b128 per tile; the LDS counter is 4 bits, a
         // whole k-step's reads cannot be outstanding); A fragments one k-step ahead, the last step requests the next layer's
         // first.
-        if (!(R8H_ABLATE && (p.debug & 4)))
+        if (!(R8H_ABLATE && (KWS_DBG(p.debug & 4))))
 #pragma unroll
             for (int t = 0; t < R8H_BDEPTH; ++t) load_b(bb[t % NB], c.qa, dB, dC, dD, t / 6, t % 6);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const AFrags& fc = fa[s & 1];
-            if (!(R8H_ABLATE && (p.debug & 8))) {
+            if (!(R8H_ABLATE && (KWS_DBG(p.debug & 8)))) {
                 if (s + 1 < KSTEPS) load_a(fa[(s + 1) & 1], ars, avoff, sb + (s + 1) * A_STEP_B, om);
                 else load_a(fa[(s + 1) & 1], ars, avoff, last ? sb : sb + A_LAYER_B, om);   // (last layer: a harmless re-read)
             }
@@ -344,7 +344,7 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
             for (int j = 0; j < 6; ++j) {
                 const int t = 6 * s + j, tn = t + R8H_BDEPTH;
                 const BFrag& bcur = bb[t % NB];
-                if (!(R8H_ABLATE && (p.debug & 4)) && tn < 6 * KSTEPS) load_b(bb[tn % NB], c.qa, dB, dC, dD, tn / 6, tn % 6);
+                if (!(R8H_ABLATE && (KWS_DBG(p.debug & 4))) && tn < 6 * KSTEPS) load_b(bb[tn % NB], c.qa, dB, dC, dD, tn / 6, tn % 6);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 5) {
                     if (s == 0) acc[j][0] = acc[j][1] = acc[j][2] = zero;
@@ -729,10 +729,17 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
         BK[2] = __builtin_amdgcn_perm(w_[5], w_[4], selk_c);                                                   \
         BK[3] = __builtin_amdgcn_perm(w_[7], w_[6], selk_c);                                                   \
     }
+            int tile_gate = 1;
+            asm volatile("" : "+s"(tile_gate));
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 f32x4 s0 = zero, s1 = zero, s2 = zero;
-                if (!(p.debug & 1)) {
+                // Each position tile's 12 window members stay in a basic block of their own behind a uniform branch hipcc cannot fold (`tile_gate`
+                // is 1, out of an empty asm): as ONE block of 60 members the pre-RA scheduler pulls the window reads of all five tiles to the
+                // front and spills 3 KB per lane (`__builtin_amdgcn_sched_barrier(0)` and a memory-clobber asm per tile do not stop it: measured,
+                // r5).  Rounds 3-4 had the experiment branch `p.debug & 1` standing here, with the same effect and the same cost (one scalar
+                // compare + branch per tile); the default build has no experiment bits any more.
+                if (tile_gate && !(KWS_DBG(p.debug & 1))) {
 #pragma unroll
                     for (int wi = 0; wi < 12; ++wi) {
                         const int oy = wi / 3, ox = wi - 3 * oy;
@@ -771,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void res8h_kernel(Res8hParams p) {
             }
             {
                 f32x4 sx = zero;
-                if (!(p.debug & 1) && w < 3) {   // wave 3 owns no extra tile
+                if (tile_gate && !(KWS_DBG(p.debug & 1)) && w < 3) {   // wave 3 owns no extra tile
 #pragma unroll
                     for (int wi = 0; wi < 12; ++wi) {
                         const int oy = wi / 3, ox = wi - 3 * oy;

@@ -99,7 +99,7 @@ __device__ __forceinline__ void r8_layer(const Res8Params& p, const Ctx& c, int 
         R8_STEP(l0[2], l1[2], l2[2], lx[2], c.qn[j] + 44 * R8_CS + (2 - 1) * R8_RS + g - 1)
     }
     f32x4 n0 = A[0], n1 = A[64], n2 = A[128], nx = A[mx * 64];
-    for (int tap = ((p.debug & 2) ? 9 : 0); tap < 9; ++tap) {
+    for (int tap = ((KWS_DBG(p.debug & 2)) ? 9 : 0); tap < 9; ++tap) {
         const int ty = tap / 3;
         const int tapoff = (ty - 1) * R8_RS + (tap - 3 * ty - 1) + g * R8_CS;
         int bt[6];
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void res8_kernel(Res8Params p) {
             for (int j = 0; j < 5; ++j) {
                 const int ad0 = lb[j] + koff[0], ad1 = lb[j] + koff[1], ad2 = lb[j] + koff[2];
                 f32x4 s0 = zero, s1 = zero, s2 = zero;
-                if (!(p.debug & 1)) {
+                if (!(KWS_DBG(p.debug & 1))) {
 #pragma unroll
                     for (int wp = 0; wp < 6; ++wp) {     // pooling-window positions two at a time: the second
                         f32x4 cc[2][3];                  // position's MFMAs cover the first one's result latency
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void res8_kernel(Res8Params p) {
             {
                 const int ad0 = lb[5] + koff[0], ad1 = lb[5] + koff[1], ad2 = lb[5] + koff[2];
                 f32x4 sx = zero;
-                if (!(p.debug & 1)) {
+                if (!(KWS_DBG(p.debug & 1))) {
 #pragma unroll
                     for (int oy = 0; oy < 4; ++oy)
 #pragma unroll
@@ -368,7 +368,7 @@ hipError_t launch_res8(const Res8Params& p, int grid, hipStream_t s) {
     }
     if (p.B <= 0) return hipSuccess;
     // p.debug bit 2 (timing experiments only): pad LDS so that only one workgroup fits a CU
-    const size_t lds = (p.debug & 4) ? (size_t)100 * 1024 : res8_lds_bytes();
+    const size_t lds = (KWS_DBG(p.debug & 4)) ? (size_t)100 * 1024 : res8_lds_bytes();
     hipLaunchKernelGGL(res8_kernel, dim3((unsigned)grid), dim3(256), lds, s, p);
     return hipGetLastError();
 }

@@ -37,3 +37,13 @@ def lib_built():
         import __graft_entry__
         __graft_entry__.build()
     return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def lib_experiments():
+    """The EXPERIMENTS=1 build (debug / timing switches, fault injection: honk2_amd/csrc/Makefile), bound beside the product library."""
+    import subprocess
+    from honk2_amd import _lib
+    subprocess.run(["make", "-C", os.path.join(ROOT, "honk2_amd", "csrc"), "EXPERIMENTS=1", "-j", str(min(8, os.cpu_count() or 1))],
+                   check=True, capture_output=True)
+    return _lib.bind(_lib.EXP_LIB_PATH)

@@ -158,6 +158,28 @@ def test_model_logits_match_reference(torch_cuda, fname):
                                  "cnn_band" if "conv_1" in cfg else "cnn_in1")
 
 
+def test_experiment_switches_do_nothing_in_the_product_library(torch_cuda, monkeypatch):
+    """A drop-in library must not compute garbage because an environment variable is set: with every ablation / timing switch of the
+    EXPERIMENTS build in the environment -- KWS_R8_DEBUG=3 (skip conv_0 and the k-loops), KWS_T3_DEBUG=7 (skip k-loops, staging, stores),
+    a phase-stamp file (host sync + copy inside the call) -- the product library still returns the golden logits on the fused res8, the
+    tiled res15 (bf16 too: pair / triple kernels) and the cnn band plan."""
+    torch = torch_cuda
+    monkeypatch.setenv("KWS_R8_DEBUG", "3")
+    monkeypatch.setenv("KWS_T3_DEBUG", "7")
+    monkeypatch.setenv("KWS_T3_TIMING", "/tmp/kws_should_never_be_written.bin")
+    monkeypatch.setenv("KWS_BAND_TIMING", "/tmp/kws_should_never_be_written.bin")
+    monkeypatch.setenv("KWS_R8_WGS_PER_CU", "1")
+    monkeypatch.setenv("KWS_TEST_THROW", "bad_alloc")
+    for fname in ("model_resnet__res8.npz", "model_resnet__res15.npz", "model_cnn__cnn-trad-pool2.npz"):
+        tag, name, cfg, sd, feats, z = load_golden_model(fname)
+        got = _build(torch, name, cfg, sd)(torch.from_numpy(feats).cuda()).cpu().numpy()
+        assert np.abs(got - z["logits"]).max() < LOGIT_TOL and (got.argmax(1) == z["logits"].argmax(1)).all(), fname
+    tag, name, cfg, sd, feats, z = load_golden_model("model_resnet__res15.npz")
+    got = _build(torch, name, dict(cfg, dtype="bf16"), sd)(torch.from_numpy(feats).cuda()).cpu().numpy()
+    assert np.abs(got - z["logits"]).max() < 2e-2
+    assert not os.path.exists("/tmp/kws_should_never_be_written.bin")
+
+
 @pytest.mark.parametrize("fname", ["model_resnet__res15.npz", "model_cnn__cnn-trad-pool2.npz", "model_resnet__res8.npz"])
 def test_reduced_precision_mode_bf16x3(torch_cuda, fname):
     """Opt-in `dtype: "bf16x3"` (BASELINE configs[2]/[4] are reduced-precision cases): three-term bf16 products,

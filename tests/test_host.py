@@ -101,18 +101,44 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol(lib_built):
             _lib.Engine(d)
 
 
-def test_no_exception_crosses_the_c_abi(lib_built, monkeypatch):
-    """include/kws.h: "never throws across the ABI".  KWS_TEST_THROW makes kws_create's body throw (std::bad_alloc or a
-    std::runtime_error) in front of the device check, so this runs without a GPU: the guard around every entry point has to turn
-    it into a code + kws_last_error(), not into std::terminate under ctypes."""
+def test_no_exception_crosses_the_c_abi(lib_built, lib_experiments, monkeypatch):
+    """include/kws.h: "never throws across the ABI".  In the EXPERIMENTS build KWS_TEST_THROW makes kws_create's body throw (std::bad_alloc
+    or a std::runtime_error) in front of the device check, so this runs without a GPU: the guard around every entry point has to turn it
+    into a code + kws_last_error(), not into std::terminate under ctypes.  The PRODUCT build has no such hook: with the variable set its
+    kws_create goes on to the device check."""
     d = _lib.make_desc(_lib.KWS_MODEL_NONE)
     h = ctypes.c_void_p()
     monkeypatch.setenv("KWS_TEST_THROW", "bad_alloc")
-    assert lib_built.kws_create(ctypes.byref(d), ctypes.byref(h)) == _lib.KWS_ENOMEM and not h.value
-    assert b"out of host memory" in lib_built.kws_last_error()
+    assert lib_experiments.kws_create(ctypes.byref(d), ctypes.byref(h)) == _lib.KWS_ENOMEM and not h.value
+    assert b"out of host memory" in lib_experiments.kws_last_error()
     monkeypatch.setenv("KWS_TEST_THROW", "synthetic failure")
-    assert lib_built.kws_create(ctypes.byref(d), ctypes.byref(h)) == _lib.KWS_EINVAL and not h.value
-    assert b"synthetic failure" in lib_built.kws_last_error()
+    assert lib_experiments.kws_create(ctypes.byref(d), ctypes.byref(h)) == _lib.KWS_EINVAL and not h.value
+    assert b"synthetic failure" in lib_experiments.kws_last_error()
+    rc = lib_built.kws_create(ctypes.byref(d), ctypes.byref(h))
+    assert b"synthetic failure" not in lib_built.kws_last_error()
+    if rc == 0:                                   # (a GPU is present: the handle is real)
+        lib_built.kws_destroy(h)
+    else:
+        assert rc == _lib.KWS_EHIP and b"no HIP device" in lib_built.kws_last_error()
+
+
+EXPERIMENT_SWITCHES = ("KWS_R8_DEBUG", "KWS_T3_DEBUG", "KWS_T3_TIMING", "KWS_T3_TIMING_LAYER", "KWS_BAND_TIMING", "KWS_TEST_THROW", "KWS_N_CU",
+                       "KWS_R8_WGS_PER_CU", "KWS_R8_GRID", "KWS_FE_WGS_PER_CU", "KWS_TILED_CHUNK", "KWS_CNN_CHUNK", "KWS_KSPLIT_MIN_STEPS",
+                       "KWS_T3_PAIR_WGS3", "KWS_T3_TRIPLE_CFG")
+
+
+def test_product_library_has_no_experiment_switches(lib_built, lib_experiments):
+    """The shipped libkws_hip.so must not compute wrong results, synchronise inside a compute call or throw on purpose because an
+    environment variable is set ("no internal sync"): the names of the experiment switches do not even occur in it.
+    They do occur in the EXPERIMENTS=1 build, which is what tools/ measures with."""
+    prod = open(_lib.LIB_PATH, "rb").read()
+    exp = open(_lib.EXP_LIB_PATH, "rb").read()
+    for name in EXPERIMENT_SWITCHES:
+        assert name.encode() not in prod, name
+        assert name.encode() in exp, name
+    # the implementation selectors that remain choose between implementations that are each parity-tested (include/kws.h lists them)
+    for name in ("KWS_RES8_IMPL", "KWS_FRONTEND_IMPL", "KWS_LAYERWISE_IMPL"):
+        assert name.encode() in prod, name
 
 
 def test_product_never_imports_the_oracle():
