@@ -351,6 +351,43 @@ def shard_record(torch, model, device, full_rate, full_k_ms, full_f_ms, full_cli
             "what": "wav -> logits on 8 192 clips = one GPU's shard of the 8-GPU run (BASELINE configs[3]); the RCCL all-gather of 393 KB of logits is not in it"}
 
 
+def config1_record(torch, model, sd, device, full_rate):
+    """BASELINE configs[1]: res8 fp32, batch 1 024, one GPU -- wav -> logits per CALL (a batch this small is two clips per persistent
+    workgroup: launch, ramp and tail effects are what it measures).  Median and mean of 200 calls after ~300 ms of load, each call bracketed by
+    events on the launch stream; efficiency = its clip rate over the full batch's; parity of ALL 1 024 clips against the fp32 CPU oracle."""
+    import numpy as np
+    from oracle import frontend, models    # bench-only use of oracle/: the checker
+    n = 1024
+    wav = synth_wav(torch, 0, n, 1234, device)
+    out = torch.empty((n, RES8["n_labels"]), dtype=torch.float32, device=device)
+    for _ in range(int(math.ceil(300.0 / max(n * EST_MS_PER_CLIP, 0.05)))):
+        model.forward_wav(wav, out=out)
+    torch.cuda.synchronize()
+    calls = 200
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(calls)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        model.forward_wav(wav, out=out)
+        b.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    med = ms[len(ms) // 2]
+    want = np.asarray(models.forward_torch("ResNet", RES8, sd, frontend.compute_mfccs_batch(wav.cpu().numpy(), "f32")))
+    par = parity_record(out.cpu().numpy(), want)
+    par["against"] = "fp32 CPU oracle (numpy front end + torch-CPU model) on all 1 024 clips"
+    return {"config": "configs[1] res8 fp32 B=1024", "plan": model.plan_name(), "dtype": "f32 (f16x3)", "batch": n,
+            "wav_to_logits": {"ms_median": med, "ms_p10": ms[len(ms) // 10], "ms_p90": ms[9 * len(ms) // 10], "calls": calls,
+                              "clips_per_s": n / med * 1e3, "ms_per_call_back_to_back_wall": 1e3 * wall / calls,
+                              "clips_per_s_back_to_back": n * calls / wall},
+            "efficiency_vs_full_batch": (n / med * 1e3) / full_rate,
+            "efficiency_vs_full_batch_back_to_back": (n * calls / wall) / full_rate,
+            "workgroups": {"clips_per_res8_workgroup": n / 512.0, "note": "512 persistent workgroups (2 per CU) take clips from a device-wide counter: at 1 024 clips a workgroup sees two"},
+            "parity": par,
+            "what": "wav -> logits on 1 024 clips per call (front end + fused res8), device-resident input; event-timed per call, and the wall time of the same 200 calls issued back to back"}
+
+
 def h2d_record(torch, model, device, nclips, pcm16=False):
     """The PCIe-inclusive variant SURVEY.md 8(d) asks for beside the headline (never `value`): the waveforms start in PINNED
     host memory; chunks of 8 192 clips are copied on a second stream while the previous chunk computes.  `pcm16`: the clips
@@ -795,6 +832,7 @@ def main():
         if world == 1 and not args.no_secondary:
             try:
                 out["secondary"] = secondary_configs(torch, device)
+                out["secondary"].append(config1_record(torch, model, sd, device, clips_per_s))
                 failed = failed or not all(r["parity"]["pass"] for r in out["secondary"])
             except Exception as exc:                   # never let an extra record take the headline line down
                 out["secondary"] = {"error": repr(exc)}

@@ -162,6 +162,8 @@ class Engine:
         with torch.cuda.device(self.device):               # kws_create binds the handle to the current HIP device
             check(self.lib.kws_create(C.byref(desc), C.byref(self.handle)), "kws_create")
         self._ws = None
+        self._captured = False      # a compute call of this engine has been captured into a graph
+        self._parked = []           # workspaces outgrown since then: captured graphs name them, so they stay alive with the engine
 
     def close(self):
         if getattr(self, "handle", None) and self.handle.value:
@@ -189,8 +191,18 @@ class Engine:
         self._ensure_ws_bytes(int(self.lib.kws_workspace_bytes(self.handle, batch, frames)))
 
     def _ensure_ws_bytes(self, need):
+        """The workspace grows with the largest call seen.  Buffers baked into a captured graph must outlive every replay
+        (include/kws.h): once a call of this engine has been captured, an outgrown workspace is kept instead of being handed
+        back to the caching allocator, and a call that would have to grow it DURING capture is refused."""
         import torch
+        capturing = torch.cuda.is_current_stream_capturing()
+        self._captured = self._captured or capturing
         if self._ws is None or self._ws.numel() < need:
+            if capturing:
+                raise RuntimeError("honk2_amd: this call needs a larger workspace and the stream is being captured -- make one un-captured "
+                                   "warm-up call with this (or a larger) batch size first")
+            if self._captured and self._ws is not None:
+                self._parked.append(self._ws)
             self._ws = None
             self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
             check(self.lib.kws_set_workspace(self.handle, C.c_void_p(self._ws.data_ptr()), self._ws.numel()),
@@ -254,7 +266,7 @@ class Engine:
                                     self._stream()), "kws_mfcc")
         return out
 
-    def forward(self, feat):
+    def forward(self, feat, out=None):
         import torch
         feat = self._check_in(feat, 3, "features")
         b, t, f = feat.shape
@@ -262,7 +274,10 @@ class Engine:
             raise ValueError(f"honk2_amd: expected {self.desc.freq} frequency bins, got {f}")
         if b:
             self._ensure_ws(b, t)
-        out = torch.empty((b, self.desc.n_labels), dtype=torch.float32, device=feat.device)
+        if out is None:
+            out = torch.empty((b, self.desc.n_labels), dtype=torch.float32, device=feat.device)
+        elif tuple(out.shape) != (b, self.desc.n_labels) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != feat.device:
+            raise ValueError("honk2_amd: `out` must be a contiguous float32 (B, n_labels) tensor on the input's device")
         if b == 0:
             return out
         check(self.lib.kws_forward(self.handle, C.c_void_p(feat.data_ptr()), b, t, C.c_void_p(out.data_ptr()),

@@ -135,11 +135,11 @@ class BaseModel(ABC, nn.Module):
             raise RuntimeError("honk2_amd models are inference-only: call model.eval() first "
                                "(BatchNorm uses running statistics, dropout is the identity)")
 
-    def forward(self, x):
-        """(B, T, F) float32 features on the GPU -> (B, n_labels) logits (one ``kws_forward`` call)."""
+    def forward(self, x, out=None):
+        """(B, T, F) float32 features on the GPU -> (B, n_labels) logits (one ``kws_forward`` call); `out`: write them into this tensor."""
         self._require_eval()
         with torch.no_grad():
-            return self.engine().forward(x)
+            return self.engine().forward(x, out)
 
     def forward_wav(self, wav, out=None, noise=None, noise_pct=0.0):
         """(B, n_samples) waveforms on the GPU -> logits, front end fused in.  float32 input -> ``kws_forward_wav``;

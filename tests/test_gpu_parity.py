@@ -890,6 +890,57 @@ def test_graph_replays_back_to_back_without_synchronisation(torch_cuda):
     assert torch.equal(model.forward_wav(srcs[0]), wants[0])      # and the eager path finds the queues as it left them
 
 
+def test_captured_features_path_survives_a_larger_eager_batch(torch_cuda):
+    """kws_forward on the fused res8 plan keeps 4 bytes per clip (the feature-range shifts) in a buffer of the handle that grows with the
+    largest batch seen.  A graph captured at a SMALL batch has that buffer's address baked into two kernel nodes; an eager call with a
+    larger batch then needs a bigger block.  The outgrown block must stay alive (it is parked until kws_destroy, include/kws.h), or the
+    next replay writes freed memory.  Capture at 64 clips, run eagerly at 4 096, replay: bit-identical to the eager 64-clip result --
+    also for a clip whose features need a shift.  And a call that would have to allocate DURING capture fails with a code, it does
+    not allocate."""
+    torch = torch_cuda
+    from oracle import weights
+    tag, name, cfg, sd, feats, z = load_golden_model("model_resnet__res8.npz")
+    model = _build(torch, name, cfg, sd)
+    small = torch.from_numpy(weights.make_features(64, seed=31)).cuda()
+    small[5] *= 40000.0                                  # beyond fp16: the shift buffer is really used
+    big = torch.from_numpy(weights.make_features(4096, seed=32)).cuda()
+    want_small = model(small).clone()
+    assert model.plan_name() == "res8_fused"
+    static_in = small.clone()
+    out = torch.empty((64, cfg["n_labels"]), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        model(static_in, out=out)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            model(static_in, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    want_big = model(big).clone()                        # grows the handle's buffer: a new block, the captured one parked
+    torch.cuda.synchronize()
+    junk = torch.full((1 << 20,), 7, dtype=torch.int32, device="cuda")    # whatever the allocator hands out next must not be what the graph writes
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want_small), float((out - want_small).abs().max())
+    assert bool((junk == 7).all()) and torch.equal(model(big), want_big)
+    # allocation under capture is refused with a code (the capture itself is abandoned by the caller)
+    huge = torch.from_numpy(weights.make_features(9000, seed=33)).cuda()
+    out_h = torch.empty((9000, cfg["n_labels"]), dtype=torch.float32, device="cuda")
+    model.forward_wav(torch.zeros((9000, 16000), device="cuda"))      # the Python host's workspace is large enough now; the library's shift buffer is not
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="warm-up"):
+            with torch.cuda.graph(g2, stream=side):
+                model(huge, out=out_h)
+    torch.cuda.synchronize()
+    assert torch.equal(model(small), want_small)         # the handle is still usable
+
+
 def test_hundred_back_to_back_replays_at_the_shard_size(torch_cuda):
     """The round-3 observation at its own scale, once: 100 replays of the captured wav -> logits graph of an 8 192-clip shard, launched
     back to back with no host synchronisation.  Then each replay took 0.14 ms instead of 1.7 (most workgroups found the work queue
@@ -1133,14 +1184,19 @@ def test_streaming_windows_read_in_place(torch_cuda, monkeypatch):
     assert f_win.shape == (n, 101, 40)
     assert torch.equal(f_win[:, 2:99], f_ref[:, 2:99])                       # the stream's own frames
     edge = [0, 1, 99, 100]
-    want = frontend.compute_mfccs_batch(np.stack([stream[i * shift:i * shift + window] for i in (0, 5, 123, 299)]), "f64")
-    for row, i in enumerate((0, 5, 123, 299)):
-        got_e, ref_e, want_e = f_win[i, edge].cpu().numpy(), f_ref[i, edge].cpu().numpy(), want[row][edge]
-        strong = want_e > want_e.max() - 9.2                                  # bands within 40 dB of the loudest (2 ln units)
-        assert np.abs(got_e - want_e)[strong].max() < 1e-3 and np.abs(ref_e - want_e)[strong].max() < 1e-3
-        assert np.abs(got_e - want_e).max() < 10 * max(np.abs(ref_e - want_e).max(), 1e-3)
+    # the 2 + 2 edge frames of EVERY window (window_edges_kernel) are held to the batched front end's own tiers against the float64
+    # restatement (test_frontend_matches_oracle): 1e-3 on bands within 40 dB of the window's strongest band, 1e-2 within 60 dB
+    wins = np.stack([stream[i * shift:i * shift + window] for i in range(n)])
+    want = frontend.compute_mfccs_batch(wins, "f64")[:, edge]
+    mel = frontend.mel_power(wins, "f64")                                    # (window, frame, band)
+    top = np.maximum(mel.max(axis=(1, 2), keepdims=True), 1e-30)
+    mel_e = mel[:, edge]
+    for name, got_e in (("windows", f_win[:, edge].cpu().numpy()), ("batched", f_ref[:, edge].cpu().numpy())):
+        err = np.abs(got_e - want)
+        assert err[mel_e > 1e-4 * top].max() < 1e-3, (name, err[mel_e > 1e-4 * top].max())
+        assert err[mel_e > 1e-6 * top].max() < 1e-2, (name, err[mel_e > 1e-6 * top].max())
     part = ap.compute_mfccs_windows(gs, window, shift, first=100, count=37)
-    assert torch.equal(part[:, 2:99], f_ref[100:137, 2:99]) and (part - f_ref[100:137]).abs().max() < 0.5
+    assert torch.equal(part[:, 2:99], f_ref[100:137, 2:99]) and torch.equal(part[:, edge], f_win[100:137][:, edge])   # a sub-range is the same bits
     l_win = model.forward_windows(gs, window, shift)
     assert (l_win - l_ref).abs().max() < LOGIT_TOL and torch.equal(l_win.argmax(1), l_ref.argmax(1))
     with pytest.raises(ValueError):
