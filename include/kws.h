@@ -22,12 +22,23 @@
  *     library BORROWS them for the duration of the call and never frees them).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every compute call is
  *     asynchronous on that stream and performs no host synchronisation and no allocation, so a call
- *     sequence can be captured into a hipGraph and replayed back to back without synchronisation (a captured call is kernel nodes only: the persistent kernels' work queues re-arm themselves) -- with two one-time exceptions, both on the FIRST compute
- *     call that needs them (so: run one un-captured warm-up call per clip length first): the re-packed
- *     parameters are uploaded when the first call after kws_load_weights finalises them, and the tiled
- *     ResNet plan (res15 / res26 / narrow models, res8 on clips that are not one second long) builds and
- *     uploads a per-layer position table the first time it sees a clip length T (blocking copies into
- *     buffers of their own; tables of earlier clip lengths are kept and never rewritten).
+ *     sequence can be captured into a hipGraph and replayed back to back without synchronisation (a captured
+ *     call is kernel nodes only: the persistent kernels' work queues re-arm themselves; tested, not
+ *     guaranteed: INTEGRATION.md section 3) -- with three exceptions, each on the FIRST compute call that
+ *     needs it (so: run one un-captured warm-up call per clip length AND at the largest batch size first):
+ *     the re-packed parameters are uploaded when the first call after kws_load_weights finalises them; the
+ *     tiled ResNet plan (res15 / res26 / narrow models, res8 on clips that are not one second long) builds
+ *     and uploads a per-layer position table the first time it sees a clip length T (blocking copies into
+ *     buffers of their own; tables of earlier clip lengths are kept and never rewritten); and kws_forward on
+ *     the fused res8 plan keeps 4 bytes per clip in a buffer of the handle that is allocated (blocking) the
+ *     first time a LARGER batch arrives -- the outgrown block is kept until kws_destroy, because a graph
+ *     captured at the smaller size still names it.  A call that would have to allocate while `stream` is
+ *     being captured returns KWS_ENOWORKSPACE instead of allocating.
+ *   - LIFETIME UNDER GRAPHS: every buffer baked into a captured graph -- the caller's input / output
+ *     buffers, the workspace given to kws_set_workspace, and the handle itself (weights, tables, queue
+ *     words) -- must outlive every replay of that graph.  Synchronise with the replaying stream before
+ *     freeing any of them, replacing the workspace, or calling kws_destroy: a replay that runs after its
+ *     buffers were unmapped is a GPU memory fault (INTEGRATION.md section 3 has the one seen in round 3).
  *   - every function returns 0 (KWS_OK) or a negative KWS_E* code; kws_last_error() returns a
  *     thread-local human-readable message for the last failure on the calling thread.
  *   - a handle is bound to the HIP device that was current at kws_create and is not re-entrant: its calls share one workspace,
@@ -43,6 +54,13 @@
  *     The front end's DFT uses the same three-term fp16 products with the samples scaled by a power of two per clip chunk
  *     (any finite sample magnitude is fine); KWS_FRONTEND_IMPL=fp32 selects its fp32-input matrix-core form, which also
  *     serves waveform rows that are not 16-byte aligned.
+ *   - Environment: the library reads a few IMPLEMENTATION SELECTORS at kws_create (or per call where noted), each choosing between
+ *     implementations that are parity-tested against the same oracle -- KWS_RES8_IMPL=bf16x6|fp32, KWS_FRONTEND_IMPL=fp32,
+ *     KWS_LAYERWISE_IMPL=nchw|fp32, KWS_FORCE_LAYERWISE=1, KWS_MATRIX_PARTS=bf16 (per call), KWS_CNN_BAND=0, KWS_CNN_IN1=0,
+ *     KWS_CNN_LIN_F16=0, KWS_T3_PAIR=0, KWS_T3_TRIPLE=0|2, KWS_WINDOWS_NO_SHARE (per call) -- and NOTHING ELSE: the ablation bits,
+ *     phase stamps, grid-size knobs and the fault-injection hook of the measurement rig exist only in `make EXPERIMENTS=1`
+ *     (libkws_hip_exp.so); no environment variable can make this library compute wrong results, synchronise inside a compute
+ *     call or throw.
  */
 #ifndef KWS_H_
 #define KWS_H_
