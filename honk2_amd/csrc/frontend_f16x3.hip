@@ -41,7 +41,7 @@ constexpr int XS = 164;                                        // LDS words per 
 #ifndef FE16_NT
 #define FE16_NT 7
 #endif
-#ifndef FE16_ABLATE   // timing experiments: 1 no power tile, 2 one k-step group per band tile in the mel stage, 4 no B-fragment builds in the k-loop (results wrong)
+#ifndef FE16_ABLATE   // timing experiments: 1 no power tile, 2 one k-step group per band tile in the mel stage, 4 no B-fragment builds in the k-loop, 8 / 16 the two mirrored single-word reads conflict-free / gone (results wrong)
 #define FE16_ABLATE 0
 #endif
 #ifndef FE16_ORDER
@@ -300,6 +300,9 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
     //      groups were tried: no faster, and the group solver's compile time explodes on a block this size.)
     struct KStep {
         int pa, pd, pb, pbs, pc, pcs;
+#if FE16_ABLATE & 8
+        int pms_abl;
+#endif
         float hj[8], hc[8];
     };
     auto setup = [&](int s, KStep& k) {
@@ -310,6 +313,9 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
         k.pbs = fb + 480 - j0 + 8 - (j0 == 0 ? 1 : 0);
         k.pc = fb + 232 - j0 + (232 - j0 >= 160 ? 4 : 0);
         k.pcs = fb + 240 - j0 + (240 - j0 >= 160 ? 4 : 0);
+#if FE16_ABLATE & 8
+        k.pms_abl = (lane & 63) + 128 * s;
+#endif
         const f32x4 h0 = *reinterpret_cast<const f32x4*>(hw + j0), h1 = *reinterpret_cast<const f32x4*>(hw + j0 + 4);
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(hw + 128 + j0), c1 = *reinterpret_cast<const f32x4*>(hw + 132 + j0);
 #pragma unroll
@@ -326,7 +332,14 @@ __global__ __launch_bounds__(256, WG_PER_CU) void frontend_f16_kernel(FrontendPa
         const f32x4 D0 = *reinterpret_cast<const f32x4*>(base + k.pd), D1 = *reinterpret_cast<const f32x4*>(base + k.pd + 4);
         const f32x4 M0 = *reinterpret_cast<const f32x4*>(base + k.pb), M1 = *reinterpret_cast<const f32x4*>(base + k.pb + 4);
         const f32x4 N0 = *reinterpret_cast<const f32x4*>(base + k.pc), N1 = *reinterpret_cast<const f32x4*>(base + k.pc + 4);
+#if FE16_ABLATE & 8      // (r5) what the four-way conflict of these two single-word reads costs: 8 = read them at one-bank-per-lane addresses instead (wrong words,
+                        // same instruction count); 16 = no reads at all (the M0 / N0 words that are there anyway: an upper bound for any bpermute / carry scheme)
+        const float MS = lds[j * TILE_WORDS + k.pms_abl], NS = lds[j * TILE_WORDS + k.pms_abl + 64];
+#elif FE16_ABLATE & 16
+        const float MS = M0[0], NS = N0[0];
+#else
         const float MS = base[k.pbs], NS = base[k.pcs];
+#endif
         const float xa[8] = {A0[0], A0[1], A0[2], A0[3], A1[0], A1[1], A1[2], A1[3]};
         const float xd[8] = {D0[0], D0[1], D0[2], D0[3], D1[0], D1[1], D1[2], D1[3]};
         const float xb[8] = {MS, M1[3], M1[2], M1[1], M1[0], M0[3], M0[2], M0[1]};

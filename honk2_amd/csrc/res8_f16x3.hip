@@ -284,6 +284,16 @@ __device__ __forceinline__ void mf_tile(int s, const u32x4 (&a)[2], const BFrag&
 #ifndef R8H_ABLATE      // 1: KWS_R8_DEBUG bits 4 / 8 drop the k-loops' LDS operand reads / weight loads (timing experiments; results are wrong)
 #define R8H_ABLATE 0
 #endif
+// (r5) what fewer MFMAs would buy at the power cap, measured instead of argued (tools/r8_levers.sh; results wrong by construction):
+//   R8H_ABLATE_K = 13 runs k-steps 0..12 only (no kind-D half step: 39 instead of 41 MFMAs per tile, layer and slot -- what a dense K of 13 steps
+//   would execute), 12 drops step 12 too (36); R8H_ABLATE_NOX = 1 skips position tile 20's MFMAs (N 336 -> 320: what a pad-free tiling of the
+//   325 positions could save at most)
+#ifndef R8H_ABLATE_K
+#define R8H_ABLATE_K R8X_KSTEPS
+#endif
+#ifndef R8H_ABLATE_NOX
+#define R8H_ABLATE_NOX 0
+#endif
 
 // phase timestamps for tools/r8_phases.py: build with -DR8H_TIMING (they overwrite the consumed feature rows)
 #ifdef R8H_TIMING
@@ -332,19 +342,24 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
         if (!(R8H_ABLATE && (KWS_DBG(p.debug & 4))))
 #pragma unroll
             for (int t = 0; t < R8H_BDEPTH; ++t) load_b(bb[t % NB], c.qa, dB, dC, dD, t / 6, t % 6);
+        constexpr int KRUN = R8H_ABLATE_K;    // = KSTEPS outside the lever experiments
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const AFrags& fc = fa[s & 1];
+            if (s >= KRUN) {   // (lever experiments only) a dropped step: no operands, no MFMAs; the next layer's first fragments still land in fa[0]
+                if (s == KSTEPS - 1) load_a(fa[0], ars, avoff, last ? sb : sb + A_LAYER_B, om);
+                continue;
+            }
             if (!(R8H_ABLATE && (KWS_DBG(p.debug & 8)))) {
-                if (s + 1 < KSTEPS) load_a(fa[(s + 1) & 1], ars, avoff, sb + (s + 1) * A_STEP_B, om);
-                else load_a(fa[(s + 1) & 1], ars, avoff, last ? sb : sb + A_LAYER_B, om);   // (last layer: a harmless re-read)
+                if (s + 1 < KRUN) load_a(fa[(s + 1) & 1], ars, avoff, sb + (s + 1) * A_STEP_B, om);
+                else if (KRUN == KSTEPS) load_a(fa[(s + 1) & 1], ars, avoff, last ? sb : sb + A_LAYER_B, om);   // (last layer: a harmless re-read)
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int t = 6 * s + j, tn = t + R8H_BDEPTH;
                 const BFrag& bcur = bb[t % NB];
-                if (!(R8H_ABLATE && (KWS_DBG(p.debug & 4))) && tn < 6 * KSTEPS) load_b(bb[tn % NB], c.qa, dB, dC, dD, tn / 6, tn % 6);
+                if (!(R8H_ABLATE && (KWS_DBG(p.debug & 4))) && tn < 6 * KRUN) load_b(bb[tn % NB], c.qa, dB, dC, dD, tn / 6, tn % 6);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j < 5) {
                     if (s == 0) acc[j][0] = acc[j][1] = acc[j][2] = zero;
@@ -367,7 +382,7 @@ __device__ __forceinline__ void x_layer(const Res8hParams& p, XCtx& c, __amdgpu_
                     }
                 } else if (c.w < 3) {   // wave 3 owns no extra tile
                     if (s == 0) accx = zero;
-                    mf_tile<TERMS>(s, fc.a[0], bcur, accx);
+                    if (!R8H_ABLATE_NOX) mf_tile<TERMS>(s, fc.a[0], bcur, accx);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
