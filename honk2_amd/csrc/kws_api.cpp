@@ -173,6 +173,7 @@ struct kws_handle {
     bool lin_in_f16 = true;                // cnn band plan, `fp16` dtype: fp16 cells between conv_1 and the first Linear (KWS_CNN_LIN_F16=0: fp32 cells, A/B and tests)
     int t3_triple = 1;                     // runs of three equal-dilation layers in one kernel (KWS_T3_TRIPLE=0: pairs + singles; 2: any three consecutive layers)
     bool t3_pair = true;                   // tiled plan, 16-bit tensors: consecutive layers of equal dilation in one kernel (KWS_T3_PAIR=0: off)
+    bool t3_stream = true;                 // tiled plan, 16-bit tensors, 41-48 channels: runs of three layers and single layers as persistent weight-stationary streams (conv3x3_stream.hip; KWS_T3_STREAM=0: the tile kernels)
     DevMem r8_shift;                       // fused res8, kws_forward: per-clip power-of-two shifts of caller-provided features (feat_shift_kernel)
     std::vector<void*> parked;             // outgrown r8_shift blocks: a captured graph may still name them, so they live as long as the handle
     DevMem range_flag;                     // device words: [0] fp16 range guard of the layer-wise plans (kws_internal.h), [16] /
@@ -791,6 +792,44 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                 // a run of exactly three layers of one dilation (res15: (4,5,6) (7,8,9) (10,11,12)), 16-bit tensors: one kernel for the run
                 // (t3_triple == 2, A/B runs: any three consecutive layers of one dilation)
                 const int Hs_i = (sh.H + dd - 1) / dd, Ws_i = (sh.W + dd - 1) / dd;
+                // (r5) any three consecutive layers of one dilation as ONE persistent weight-stationary stream (conv3x3_stream.hip); bit-identical to the forms below
+                if (m_terms == 1 && h->t3_stream && i + 2 <= d.n_layers && resnet_dilation(d, i + 1) == dd && resnet_dilation(d, i + 2) == dd &&
+                    conv3x3_stream_supported(C, Ws_i)) {
+                    const int ld_out3 = i + 2 < d.n_layers ? ilog2(resnet_dilation(d, i + 3)) : 0;
+                    std::unique_ptr<ConvLayer::PosTab>& pt3 = h->rconv[i].postabs3[T];
+                    if (!pt3) {
+                        std::vector<int> tab;
+                        std::unique_ptr<ConvLayer::PosTab> fresh(new ConvLayer::PosTab);
+                        build_tile_conv_table(sh.H, sh.W, ld_in, ld_out3, ld_x, tab, fresh->cpc[0], fresh->cpc[1], fresh->cpc[2]);
+                        if ((rc = fresh->mem.upload(tab.data(), tab.size() * sizeof(int)))) { h->rconv[i].postabs3.erase(T); return rc; }
+                        pt3 = std::move(fresh);
+                    }
+                    StreamConvParams sp{};
+                    sp.first_even = even ? 1 : 0;
+                    sp.n_layers = 3;
+                    sp.in = even ? Y : xc;
+                    sp.res = even ? xc : nullptr;
+                    sp.out = even ? xn : Y;
+                    sp.out2 = even ? nullptr : xn;
+                    sp.f16 = m_f16;
+                    for (int u = 0; u < 3; ++u) {
+                        const ConvLayer& L = h->rconv[i + u];
+                        sp.apk[u] = m_f16 ? L.apk_t3h.as<unsigned short>() : L.apk16.as<unsigned short>();
+                        sp.inv_scale[u] = m_f16 ? 1.0f / L.t3h_scale : 1.0f;
+                        sp.border[u] = L.has_border ? L.border_pad.as<float>() : nullptr;
+                    }
+                    sp.B = nb; sp.Ws = Ws_i;
+                    sp.total = nb * dd * dd * Hs_i * Ws_i;
+                    sp.rg = rg;
+                    sp.postab = pt3->mem.as<int>();
+                    sp.cpc_in = pt3->cpc[0]; sp.cpc_out = pt3->cpc[1]; sp.cpc_res = pt3->cpc[2];
+                    HIP_TRY(launch_conv3x3_stream(sp, C, h->n_cu, s));
+                    if (first_pass) note_layers("stream", i, 3);
+                    std::swap(xc, xn);
+                    ld_x = even ? ld_out3 : ld_in;
+                    i += 2;
+                    continue;
+                }
                 if (m_terms == 1 && h->t3_pair && h->t3_triple && i + 2 <= d.n_layers && resnet_dilation(d, i + 1) == dd &&
                     resnet_dilation(d, i + 2) == dd &&
                     (h->t3_triple == 2 || ((i == 1 || resnet_dilation(d, i - 1) != dd) && (i + 3 > d.n_layers || resnet_dilation(d, i + 3) != dd))) &&
@@ -925,8 +964,22 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                     if ((rc = t3_buf.upload(z.data(), z.size() * 8))) return rc;
                     tp.dbg_ts = t3_buf.as<unsigned long long>();
                 }
-                HIP_TRY(launch_conv3x3_tile(tp, C, s));
-                if (first_pass) note_layers("conv", i, 1);
+                const bool stream1 = m_terms == 1 && h->t3_stream && !t3_this && conv3x3_stream_supported(C, tp.Ws);
+                if (stream1) {   // (r5) a single layer as a persistent weight-stationary stream: the same tensors, table and bits
+                    StreamConvParams sp{};
+                    sp.first_even = even ? 1 : 0;
+                    sp.n_layers = 1;
+                    sp.in = tp.in; sp.res = tp.res; sp.out = tp.out; sp.out2 = nullptr;
+                    sp.f16 = tp.f16;
+                    sp.apk[0] = tp.apk16; sp.inv_scale[0] = tp.inv_scale; sp.border[0] = tp.border;
+                    sp.B = nb; sp.Ws = tp.Ws; sp.total = tp.total; sp.rg = rg;
+                    sp.postab = tp.postab;
+                    sp.cpc_in = tp.cpc_in; sp.cpc_out = tp.cpc_out; sp.cpc_res = tp.cpc_res;
+                    HIP_TRY(launch_conv3x3_stream(sp, C, h->n_cu, s));
+                } else {
+                    HIP_TRY(launch_conv3x3_tile(tp, C, s));
+                }
+                if (first_pass) note_layers(stream1 ? "stream" : "conv", i, 1);
                 if (t3_this) {
                     std::vector<unsigned long long> z((size_t)8192 * 4 * 8);
                     HIP_TRY(hipStreamSynchronize(s));
@@ -1317,6 +1370,7 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
     if (const char* tp = std::getenv("KWS_T3_TRIPLE")) h->t3_triple = std::atoi(tp);
     if (const char* tp = std::getenv("KWS_CNN_LIN_F16")) h->lin_in_f16 = std::atoi(tp) != 0;
     if (const char* tp = std::getenv("KWS_T3_PAIR")) h->t3_pair = std::atoi(tp) != 0;   // A/B and tests: 0 = one kernel per layer
+    if (const char* tp = std::getenv("KWS_T3_STREAM")) h->t3_stream = std::atoi(tp) != 0;   // A/B and tests: 0 = tile / pair / triple kernels only
     int rc = setup_frontend(h.get());
     if (rc) return rc;
     const unsigned zero_word[64] = {0};

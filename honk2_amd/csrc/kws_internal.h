@@ -445,6 +445,29 @@ struct TripleConvParams {
 };
 bool conv3x3_triple_supported(int C, int Ws, bool first_even);
 hipError_t launch_conv3x3_triple(const TripleConvParams& p, int C, hipStream_t s);
+// (r5) The same runs -- three consecutive layers of equal dilation, or one layer -- as a persistent, weight-stationary STREAM (conv3x3_stream.hip):
+// one workgroup per CU, a layer's weights in one wave's registers, the layers of a run as three waves 112 positions apart on LDS rings, a loader
+// wave in front of them.  Tensors, tables, parities and results are the triple / single tile kernels' (bit for bit).
+struct StreamConvParams {
+    const void* in;        // CL 16-bit tensor in layout(2^ld)
+    const void* res;       // first layer even: x_{a-2} in layout(2^ld_res) (cells through the table); else nullptr
+    void* out;             // the last layer's output, written in layout(2^ld_out) (cells through the table)
+    void* out2;            // three layers, a odd: x_{a+1}, written in the input's own layout (cell = flattened position); else nullptr
+    const unsigned short* apk[3];   // weights in the fragment order of the single-layer tile kernel
+    const float* border[3];         // (16, 48) border-bias tables, or nullptr
+    float inv_scale[3];             // 2^-S of the fp16 weights (1 for bf16)
+    int first_even;        // parity of a
+    int n_layers;          // 1 or 3
+    int B;                 // clips (for the 32-bit offset check only)
+    int Ws, total;         // sub-map width and cells of the input layout (as TileConvParams)
+    int f16;               // operand / tensor type: fp16 (1) or bf16 (0)
+    RangeGate rg;
+    const int* postab;     // build_tile_conv_table(H, W, ld, ld_out, ld_res)
+    int cpc_in, cpc_out, cpc_res;
+    int span;              // set by the launcher: positions per workgroup (a multiple of 16)
+};
+bool conv3x3_stream_supported(int C, int Ws);
+hipError_t launch_conv3x3_stream(const StreamConvParams& p, int C, int n_cu, hipStream_t s);
 // First conv of the cnn-* models from an LDS image of the clip (conv_in1.hip): Cin == 1, kw == 8, no padding, fused MaxPool
 struct In1ConvParams {
     const float* feat;     // (B, T, F) fp32 feature maps

@@ -584,6 +584,7 @@ def test_layer_pairs_in_one_kernel_are_bit_identical(torch_cuda, dtype, case, mo
         cfg, n, t = {"n_feature_maps": 45, "n_layers": 24, "use_dilation": False, "pool": [2, 2], "n_labels": 12}, 300, 101
     else:
         cfg, n, t = {"n_feature_maps": 45, "n_layers": 24, "use_dilation": True, "n_labels": 2}, 9, 901
+    monkeypatch.setenv("KWS_T3_STREAM", "0")      # the tile / pair / triple kernels themselves (the streams of conv3x3_stream.hip have their own test below)
     sd = weights.make_state_dict("ResNet", cfg, seed=11)
     x = torch.from_numpy(weights.make_features(n, seed=12, time=t)).cuda()
     monkeypatch.setenv("KWS_T3_PAIR", "1")
@@ -615,6 +616,7 @@ def test_layer_triples_in_one_kernel_are_bit_identical(torch_cuda, dtype, case, 
         cfg, n, t = {"n_feature_maps": 45, "n_layers": 24, "use_dilation": True, "n_labels": 2}, 9, 901
     else:
         cfg, n, t = {"n_feature_maps": 45, "n_layers": 12, "use_dilation": True, "n_labels": 12}, 3, 37
+    monkeypatch.setenv("KWS_T3_STREAM", "0")      # the tile / pair / triple kernels themselves (the streams of conv3x3_stream.hip have their own test below)
     sd = weights.make_state_dict("ResNet", cfg, seed=11)
     x = torch.from_numpy(weights.make_features(n, seed=12, time=t)).cuda()
     outs, plans = {}, {}
@@ -642,12 +644,56 @@ def test_layer_triples_in_one_kernel_are_bit_identical(torch_cuda, dtype, case, 
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ["res15", "res26", "hey_snips", "short", "tiny", "pooled", "five"])
+def test_layer_streams_are_bit_identical(torch_cuda, dtype, case, monkeypatch):
+    """16-bit tensors, 41-48 channels (round 5, conv3x3_stream.hip): any three consecutive layers of one dilation, and any single layer, run as
+    a persistent weight-stationary stream -- a layer's weights in one wave's registers, the three layers as three waves 112 positions apart on
+    LDS rings, a loader wave in front (reference model/resnet.py:20-26, 44-56).  Same fragments, same K order, same epilogue, same rounding of
+    the intermediate maps: the logits must equal the one-kernel-per-layer tile form bit for bit -- res15 (runs at dilations 1, 2, 4, 8 + layer
+    13 alone at 16), res26 (eight runs on the pooled map), hey_snips (901 frames, dilations to 128: sub-maps three cells wide), a 37-frame
+    12-layer model, one 23-frame clip (spans shorter than the pipeline), a (3, 2)-pooled map and a five-layer model (a run + two singles); batches
+    that span many workgroups and a chunk boundary."""
+    torch = torch_cuda
+    from oracle import weights
+    cfg, n, t = {
+        "res15": ({"n_feature_maps": 45, "n_layers": 13, "use_dilation": True, "n_labels": 12}, 1100, 101),
+        "res26": ({"n_feature_maps": 45, "n_layers": 24, "use_dilation": False, "pool": [2, 2], "n_labels": 12}, 300, 101),
+        "hey_snips": ({"n_feature_maps": 45, "n_layers": 24, "use_dilation": True, "n_labels": 2}, 9, 901),
+        "short": ({"n_feature_maps": 45, "n_layers": 12, "use_dilation": True, "n_labels": 12}, 3, 37),
+        "tiny": ({"n_feature_maps": 45, "n_layers": 6, "use_dilation": True, "n_labels": 12}, 1, 23),
+        "pooled": ({"n_feature_maps": 41, "n_layers": 8, "use_dilation": False, "pool": [3, 2], "n_labels": 12}, 70, 64),
+        "five": ({"n_feature_maps": 48, "n_layers": 5, "use_dilation": False, "n_labels": 7}, 33, 50),
+    }[case]
+    sd = weights.make_state_dict("ResNet", cfg, seed=11)
+    x = torch.from_numpy(weights.make_features(n, seed=12, time=t)).cuda()
+    monkeypatch.setenv("KWS_T3_STREAM", "1")
+    fused = _build(torch, "ResNet", dict(cfg, dtype=dtype), sd)
+    got = fused(x)
+    assert fused.plan_name() == "resnet_tiled"
+    plan = fused.plan_detail()
+    if case == "res15":
+        assert plan == "conv0 stream(1,2,3) stream(4,5,6) stream(7,8,9) stream(10,11,12) stream(13) mean+linear", plan
+    elif case in ("res26", "hey_snips"):
+        assert plan.count("stream(") == 8 and "pair" not in plan and "triple" not in plan and "conv(" not in plan, plan
+    elif case == "five":
+        assert plan == "conv0 stream(1,2,3) stream(4) stream(5) mean+linear", plan
+    monkeypatch.setenv("KWS_T3_STREAM", "0")
+    monkeypatch.setenv("KWS_T3_PAIR", "0")
+    plain = _build(torch, "ResNet", dict(cfg, dtype=dtype), sd)
+    want = plain(x)
+    assert "stream" not in plain.plan_detail() and "pair" not in plain.plan_detail()
+    assert torch.isfinite(got).all() and torch.equal(got, want), (case, dtype, float((got - want).abs().max()))
+    assert torch.equal(fused(x[: max(1, n // 3)]), want[: max(1, n // 3)])          # a clip's logits do not depend on its batch
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_layer_pairs_on_odd_shapes(torch_cuda, dtype, monkeypatch):
     """The pair kernel where no shipped config puts it: maps smaller than one workgroup tile (a batch of one 23-frame clip), a map whose
     flattened positions end inside a tile, a pooled map, dilations that reach past the map, 19 and 45 channels.  Bit-identical to the
     one-kernel-per-layer form, and within the 16-bit tolerance of the fp32 oracle (reference model/resnet.py:38-60)."""
     torch = torch_cuda
     from oracle import models, weights
+    monkeypatch.setenv("KWS_T3_STREAM", "0")
     rng = np.random.default_rng(31)
     for cfg, T, B in [
         ({"n_feature_maps": 45, "n_layers": 6, "use_dilation": True, "n_labels": 12}, 23, 1),
