@@ -197,7 +197,9 @@ struct StreamHalf {
 template <int NM>
 struct StreamWaveState {     // what a compute wave keeps across steps (registers)
     su32x4 A[S_STEPS][NM];
-    int ktap[S_STEPS];
+    int ktap[5];                // taps of the five k-steps whose lane groups straddle two taps (s = 1, 4, 7, 10, 13)
+    int base[S_STEPS];          // LDS address of tile 0's B fragment of k-step s in the CURRENT step (advanced by 64 cells per step)
+    int tmk[4], ocl[4];         // the current step's records: tap mask | border class << 9 | valid << 13, output cell (read at the end of the step before)
     su32x2 res_next[4][NM];   // a residual that comes from memory: requested one step ahead (the step before consumes what this one requested)
     unsigned amax;
 };
@@ -228,7 +230,36 @@ __device__ __forceinline__ void stream_request_residual(const StreamConvParams& 
     }
 }
 
-// one step of one compute wave: four position tiles starting at the (wave-uniform, 64-aligned) position p_step, this wave's channel tiles
+// records of the step that starts at p_step into the wave state (tap-mask word, output cell) -- read one step ahead, at the END of the step before
+template <bool F16, int L, bool EVEN, int ELL, int HALF>
+__device__ __forceinline__ void stream_fetch_records(const StreamConvParams& p, StreamWaveState<StreamHalf<HALF>::NM>& st, const int p_step, const int X0,
+                                                     const int need_lo, const int need_hi, const int pcol) {
+    using R = StreamRole<F16, L, EVEN, ELL>;
+    using C = StreamCfg<L>;
+    using M = StreamLds<L>;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p0 = p_step + 16 * k;
+        const int ra = M::REC + ((((p0 - X0) & (C::RREC - 1)) + pcol) << 4);
+        if (R::LAST) {
+            const su32x2 e = s_read8(ra);
+            st.tmk[k] = (int)e[0];
+            st.ocl[k] = (int)e[1];
+        } else {
+            st.tmk[k] = *reinterpret_cast<const int __attribute__((address_space(3)))*>((unsigned)ra);
+            st.ocl[k] = 0;
+        }
+        const int pl = p0 + pcol;
+        // outside the tensor, or a tile nobody needs from this layer (only at the two ends of a span): no live tap, no epilogue -- the tile still
+        // runs its MFMAs on zeros, so the k-loop has no run-time branch
+        if (!((unsigned)pl < (unsigned)p.total) || p0 + 16 <= need_lo || p0 >= need_hi) st.tmk[k] = 0;
+    }
+}
+
+// one step of one compute wave: four position tiles starting at the (wave-uniform, 64-aligned) position p_step, this wave's channel tiles.
+// Software-pipelined by hand, one scheduling fence per k-step: [MFMAs of (tile k, k-step s)] [B fragment eight k-steps ahead] [a slice of tile k - 1's
+// epilogue]; a tile's border bias / LDS residual are requested at its k-step 5 and consumed with the next tile's first k-steps, so the wave neither
+// drains the matrix pipe for an epilogue nor waits on an LDS round trip inside one.
 template <bool F16, int L, bool EVEN, int ELL, int HALF>
 __device__ __forceinline__ void stream_compute_step(const StreamConvParams& p, StreamWaveState<StreamHalf<HALF>::NM>& st, const int p_step, const int X0, const int S0,
                                                     const int S1, const int need_lo, const int need_hi, const int g, const int pcol, const int lane, const int rstage) {
@@ -238,7 +269,6 @@ __device__ __forceinline__ void stream_compute_step(const StreamConvParams& p, S
     using HF = StreamHalf<HALF>;
     constexpr int NM = HF::NM;
     // slots of the step's first tile in the rings: steps are 64-aligned and every ring is a multiple of 64 long, so tile k sits 16 k slots on
-    const int s_in = s_mod(p_step - X0, R::IN_R);
     const int s_out = R::LAST ? 0 : s_mod(p_step - X0, R::OUT_R);
     const int s_res = R::RES == 2 ? s_mod(p_step - X0, R::RES_R) : 0;
     const float inv_scale = p.inv_scale[ELL];
@@ -252,97 +282,115 @@ __device__ __forceinline__ void stream_compute_step(const StreamConvParams& p, S
             for (int m = 0; m < NM; ++m) s_write8(rstage + ((k * 3 + HF::M0 + m) * 64 + lane) * 8, st.res_next[k][m]);
         stream_request_residual<F16, L, HALF>(p, st, p_step + C::S, X0, need_lo, need_hi, g, pcol);
     }
-    // records of the four tiles first: tap mask word, and the output cell where this layer stores to memory
-    int tmk[4], ocl[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int p0 = p_step + 16 * k;
-        const int ra = M::REC + ((((p0 - X0) & (C::RREC - 1)) + pcol) << 4);
-        if (R::LAST) {
-            const su32x2 e = s_read8(ra);
-            tmk[k] = (int)e[0];
-            ocl[k] = (int)e[1];
-        } else {
-            tmk[k] = *reinterpret_cast<const int __attribute__((address_space(3)))*>((unsigned)ra);
-            ocl[k] = 0;
-        }
-        const int pl = p0 + pcol;
-        // outside the tensor, or a tile nobody needs from this layer (only at the two ends of a span): no live tap, no epilogue -- the tile still
-        // runs its MFMAs on zeros, so the k-loop has no run-time branch
-        if (!((unsigned)pl < (unsigned)p.total) || p0 + 16 <= need_lo || p0 >= need_hi) tmk[k] = 0;
-    }
-    // B fragments: address of tile 0's fragment of k-step s; tile k adds 16 k cells as the read's immediate offset.  A dead tap's address is 0 -- the
-    // zero region at the bottom of LDS is long enough for the four immediates.
-    int base[S_STEPS];
-    {
-        const int lb = R::IN_ADDR + (s_in + pcol) * SC;
-        si32x4 ko[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ko[q] = *reinterpret_cast<s_lds_i32x4_cptr>((unsigned)(M::KOFF + g * 64 + q * 16));
-#pragma unroll
-        for (int s = 0; s < S_STEPS; ++s) base[s] = lb + ko[s >> 2][s & 3];
-    }
-    // B fragments: a ring of NBUF registers over the step's 4 x 14 (tile, k-step) sequence -- fragment i + NBUF is requested right behind the MFMAs that
-    // consume fragment i (eight k-steps = 128 - 256 matrix clocks of look-ahead; the partner wave of the SIMD covers the rest)
+    // B fragments: st.base[s] is the address of tile 0's fragment of k-step s; tile k adds 16 k cells as the read's immediate offset.  A dead tap's
+    // address is 0 -- the zero region at the bottom of LDS is long enough for the four immediates.  A ring of NBUF registers runs over the step's
+    // 4 x 14 (tile, k-step) sequence: fragment i + NBUF is requested right behind the MFMAs that consume fragment i.
     constexpr int NBUF = 8, NSEQ = 4 * S_STEPS;
     su32x4 b[NBUF];
+    // tap of (k-step s, lane group g): block 4 s + g of 6 per tap.  In nine k-steps all four lane groups share a tap (an immediate); in the other five
+    // (s = 1, 4, 7, 10, 13) groups 2, 3 are one tap further (a per-lane register; 31 = the zero-weight padding blocks of k-step 13, bit 31 is never set)
+#ifndef STREAM_ABLATE   // (experiments, results wrong) 1: no B-fragment reads after the first eight; 2: no MFMAs; 4: no epilogues; 8: B reads without the tap mask
+#define STREAM_ABLATE 0
+#endif
 #define S_LOADB(I_)                                                                                             \
-    {                                                                                                           \
+    if (!((STREAM_ABLATE & 1) && (I_) >= NBUF)) {                                                               \
         constexpr int k_ = (I_) / S_STEPS, s_ = (I_) % S_STEPS;                                                 \
-        const int msk_ = __builtin_amdgcn_sbfe(tmk[k_], st.ktap[s_], 1); /* 0 or -1 */                          \
-        b[(I_) % NBUF] = *reinterpret_cast<s_lds_u32x4_cptr>((unsigned)(base[s_] & msk_) + k_ * 16 * SC);       \
+        int msk_; /* 0 or -1 */                                                                                 \
+        if (s_ % 3 == 1) msk_ = __builtin_amdgcn_sbfe(st.tmk[k_], st.ktap[s_ / 3], 1);                          \
+        else asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(msk_) : "v"(st.tmk[k_]), "n"((4 * s_) / 6));                  \
+        b[(I_) % NBUF] = *reinterpret_cast<s_lds_u32x4_cptr>((unsigned)(st.base[s_] & msk_) + k_ * 16 * SC);    \
     }
     stream_unroll<0, NBUF>([&](auto ic) { S_LOADB(decltype(ic)::value) });
-    f32x4 acc[NM];
-    stream_unroll<0, NSEQ>([&](auto ic) {
-        constexpr int i = decltype(ic)::value, k = i / S_STEPS, s = i % S_STEPS;
-        if (s == 0) {
-#pragma unroll
-            for (int m = 0; m < NM; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            if (F16) SMFH(st.A[s][m], b[i % NBUF], acc[m]);
-            else SMFB(st.A[s][m], b[i % NBUF], acc[m]);
-        }
-        if (i + NBUF < NSEQ) S_LOADB(i + NBUF < NSEQ ? i + NBUF : 0)
-        if (s == S_STEPS - 1) {
-        const int p0 = p_step + 16 * k;
-        const int tm = tmk[k];
-        // ---- epilogue of this wave's channel tiles
+    f32x4 acc[2][NM];          // by tile parity: the next tile's chain starts while the last one's epilogue runs
+    f32x4 ebb[NM];             // border bias of the tile whose epilogue comes next
+    su32x2 erv[NM];            // ... and its residual (from the LDS ring or the wave's parked block)
+    // epilogue of (tile k, channel-tile slot m): relu(fma(acc, 2^-S, bias)) + residual -> round -> ring / memory
+    auto epilogue = [&](auto kc, auto mc) {
+        constexpr int k = decltype(kc)::value, m = decltype(mc)::value;
+        const int tm = st.tmk[k];
         if ((tm >> 13) & 1) {
-            const int pl = p0 + pcol;
-            const int bmask = (tm >> 9) & 15;
+            const int pl = p_step + 16 * k + pcol;
             const bool own = pl >= S0 && pl < S1;
             const int so = s_out + 16 * k;
+            const int co0 = (HF::M0 + m) * 16 + 4 * g;
+            f32x4 rv = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (R::RES != 0) rv = s_unpack4<F16>(erv[m]);
+            f32x4 v;
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const int co0 = (HF::M0 + m) * 16 + 4 * g;
-                const f32x4 bb = *reinterpret_cast<s_lds_f32x4_cptr>((unsigned)(M::BORDER + ((ELL * 16 + bmask) * 48 + co0) * 4));
-                f32x4 rv = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (R::RES == 1) rv = s_unpack4<F16>(s_read8(rstage + ((k * 3 + HF::M0 + m) * 64 + lane) * 8));   // (parked at the top of the step)
-                if (R::RES == 2) rv = s_unpack4<F16>(s_read8(R::RES_ADDR + (s_res + 16 * k + pcol) * SC + co0 * 2));
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = s_relu1(fmaf(acc[m][r], inv_scale, bb[r])) + rv[r];   // (x + 0 = x exactly for x >= +0: the same bits as without a residual)
-                    if (F16) st.amax = max(st.amax, __builtin_bit_cast(unsigned, v[r]));   // bit patterns: every stored value is >= +0; a NaN or a sign bit reads as huge
-                }
-                const su32x2 pk = s_pack4<F16>(v);
-                if (!R::LAST) {
-                    const int oa = R::OUT_ADDR + (so + pcol) * SC + co0 * 2;
-                    s_write8(oa, pk);
-                    if (so < R::OUT_G) s_write8(oa + R::OUT_R * SC, pk);               // (uniform) the guard copy behind the ring
-                    if (so >= R::OUT_R - R::OUT_G) s_write8(oa - R::OUT_R * SC, pk);   // (uniform) ... in front of it
-                } else if (own) {
-                    *reinterpret_cast<su32x2*>(outp + (size_t)ocl[k] * SC + co0 * 2) = pk;
-                }
-                if (R::OUT2 && own) *reinterpret_cast<su32x2*>(out2p + (size_t)pl * SC + co0 * 2) = pk;
+            for (int r = 0; r < 4; ++r) {
+                v[r] = s_relu1(fmaf(acc[k & 1][m][r], inv_scale, ebb[m][r])) + rv[r];   // (x + 0 = x exactly for x >= +0: the same bits as without a residual)
+                if (F16) st.amax = max(st.amax, __builtin_bit_cast(unsigned, v[r]));      // bit patterns: every stored value is >= +0; a NaN or a sign bit reads as huge
             }
+            const su32x2 pk = s_pack4<F16>(v);
+            if (STREAM_ABLATE & 48) asm volatile("" ::"v"(pk));     // (experiments) 16: no stores to memory; 32: no ring writes
+            if (!R::LAST && !(STREAM_ABLATE & 32)) {
+                const int oa = R::OUT_ADDR + (so + pcol) * SC + co0 * 2;
+                s_write8(oa, pk);
+                if (so < R::OUT_G) s_write8(oa + R::OUT_R * SC, pk);               // (uniform) the guard copy behind the ring
+                if (so >= R::OUT_R - R::OUT_G) s_write8(oa - R::OUT_R * SC, pk);   // (uniform) ... in front of it
+            } else if (R::LAST && own && !(STREAM_ABLATE & 16)) {
+                *reinterpret_cast<su32x2*>(outp + (size_t)st.ocl[k] * SC + co0 * 2) = pk;
+            }
+            if (R::OUT2 && own && !(STREAM_ABLATE & 16)) *reinterpret_cast<su32x2*>(out2p + (size_t)pl * SC + co0 * 2) = pk;
         }
+    };
+    // the operands of tile k's epilogue: requested while its k-loop still runs
+    auto epilogue_operands = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const int bmask = (st.tmk[k] >> 9) & 15;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int co0 = (HF::M0 + m) * 16 + 4 * g;
+            ebb[m] = *reinterpret_cast<s_lds_f32x4_cptr>((unsigned)(M::BORDER + ((ELL * 16 + bmask) * 48 + co0) * 4));
+            if (R::RES == 1) erv[m] = s_read8(rstage + ((k * 3 + HF::M0 + m) * 64 + lane) * 8);   // (parked at the top of the step)
+            if (R::RES == 2) erv[m] = s_read8(R::RES_ADDR + (s_res + 16 * k + pcol) * SC + co0 * 2);
         }
+    };
+    stream_unroll<0, NSEQ>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, k = i / S_STEPS, s = i % S_STEPS;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            if (s == 0) acc[k & 1][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (STREAM_ABLATE & 2) acc[k & 1][m][0] += __builtin_bit_cast(float, b[i % NBUF][0]);
+            else if (F16) SMFH(st.A[s][m], b[i % NBUF], acc[k & 1][m]);
+            else SMFB(st.A[s][m], b[i % NBUF], acc[k & 1][m]);
+        }
+        if (i + NBUF < NSEQ) S_LOADB(i + NBUF < NSEQ ? i + NBUF : 0)
+        if (!(STREAM_ABLATE & 4) && k >= 1 && s >= 1 && s <= NM) epilogue(std::integral_constant<int, (k >= 1 ? k - 1 : 0)>{}, std::integral_constant<int, (s >= 1 && s <= NM ? s - 1 : 0)>{});
+        if (s == 5) epilogue_operands(std::integral_constant<int, k>{});   // (behind the previous tile's epilogue, which has consumed ebb / erv by k-step NM)
+        __builtin_amdgcn_sched_barrier(0);
     });
+    if (!(STREAM_ABLATE & 4)) stream_unroll<0, NM>([&](auto mc) { epilogue(std::integral_constant<int, 3>{}, mc); });
+    else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int m = 0; m < NM; ++m) asm volatile("" ::"v"(acc[q][m]));
+    }
 #undef S_LOADB
+    // the next step's records, and its fragment addresses: one step on in the input ring (or back to its start)
+    stream_fetch_records<F16, L, EVEN, ELL, HALF>(p, st, p_step + C::S, X0, need_lo, need_hi, pcol);
+    {
+        const int s_in = s_mod(p_step - X0, R::IN_R);
+        const int delta = (s_in + C::S >= R::IN_R ? C::S - R::IN_R : C::S) * SC;      // (uniform; a step never straddles the ring's end)
+#pragma unroll
+        for (int s = 0; s < S_STEPS; ++s) st.base[s] += delta;
+    }
+}
+
+// before a wave's first step: its records and fragment addresses
+template <bool F16, int L, bool EVEN, int ELL, int HALF>
+__device__ __forceinline__ void stream_prime(const StreamConvParams& p, StreamWaveState<StreamHalf<HALF>::NM>& st, const int p_step, const int X0, const int need_lo,
+                                             const int need_hi, const int g, const int pcol) {
+    using R = StreamRole<F16, L, EVEN, ELL>;
+    using M = StreamLds<L>;
+    stream_fetch_records<F16, L, EVEN, ELL, HALF>(p, st, p_step, X0, need_lo, need_hi, pcol);
+    const int lb = R::IN_ADDR + (s_mod(p_step - X0, R::IN_R) + pcol) * SC;
+    si32x4 ko[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ko[q] = *reinterpret_cast<s_lds_i32x4_cptr>((unsigned)(M::KOFF + g * 64 + q * 16));
+#pragma unroll
+    for (int s = 0; s < S_STEPS; ++s) st.base[s] = lb + ko[s >> 2][s & 3];
 }
 
 // everything a compute wave does, for one half of one layer
@@ -370,10 +418,9 @@ __device__ __forceinline__ void stream_compute_wave(const StreamConvParams& p, c
 #pragma unroll
             for (int m = 0; m < HF::NM; ++m) asm volatile("" : "+v"(st.A[s][m]));
 #pragma unroll
-        for (int s = 0; s < S_STEPS; ++s) {
-            const int bi = 4 * s + g, tap = bi / 6;
-            st.ktap[s] = tap < 9 ? tap : 31;                         // (zero-weight padding blocks test bit 31 of the mask word, never set)
-            asm volatile("" : "+v"(st.ktap[s]));                     // (opaque: where all four lane groups share a tap hipcc folds the bit-field extract into and + compare + select)
+        for (int q = 0; q < 5; ++q) {
+            const int bi = 4 * (3 * q + 1) + g, tap = bi / 6;
+            st.ktap[q] = tap < 9 ? tap : 31;                         // (zero-weight padding blocks test bit 31 of the mask word, never set)
         }
     }
     const int need_margin = (L - 1 - ell) * H;
@@ -381,9 +428,24 @@ __device__ __forceinline__ void stream_compute_wave(const StreamConvParams& p, c
     const int rstage = StreamLds<L>::RSTAGE + (L == 3 ? 0 : lw) * StreamLds<L>::RSTAGE_BYTES;   // (used by a first layer whose residual comes from memory)
     const int x_wave = L == 3 ? X0 - ell * C::LAG : X0 + lw * 64;    // where this wave's stream starts (a single layer: three thirds of a 192-position step)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the workgroup's set-up barrier)
+#ifdef STREAM_TIMING   // (experiments) where a wave's time goes: cycles in its own work / at the step barrier, printed by two workgroups
+    unsigned long long tw_work = 0, tw_bar = 0, tw0 = __builtin_readcyclecounter();
+#define ST_T(x) x
+#else
+#define ST_T(x)
+#endif
     for (int t = S_T_START; t < NT; ++t) {
+        ST_T(const unsigned long long ta = __builtin_readcyclecounter();)
         if (t == -1) {
-            // a first layer whose residual comes from memory requests step 0's before step 0 (layer 0 of an even-first run / an even single layer)
+            // step 0's records and fragment addresses; a first layer whose residual comes from memory requests step 0's (layer 0 of an even-first run /
+            // an even single layer)
+            if (L == 3) {
+                if (ell == 0) stream_prime<F16, L, EVEN, 0, HALF>(p, st, x_wave, X0, need_lo, need_hi, g, pcol);
+                else if (ell == 1) stream_prime<F16, L, EVEN, L == 3 ? 1 : 0, HALF>(p, st, x_wave, X0, need_lo, need_hi, g, pcol);
+                else stream_prime<F16, L, EVEN, L == 3 ? 2 : 0, HALF>(p, st, x_wave, X0, need_lo, need_hi, g, pcol);
+            } else {
+                stream_prime<F16, L, EVEN, 0, HALF>(p, st, x_wave, X0, need_lo, need_hi, g, pcol);
+            }
             if (EVEN && ell == 0) stream_request_residual<F16, L, HALF>(p, st, x_wave, X0, need_lo, need_hi, g, pcol);
         } else if (t >= 0) {
             const int p_step = x_wave + t * C::S;
@@ -395,8 +457,15 @@ __device__ __forceinline__ void stream_compute_wave(const StreamConvParams& p, c
                 stream_compute_step<F16, L, EVEN, 0, HALF>(p, st, p_step, X0, S0, S1, need_lo, need_hi, g, pcol, lane, rstage);
             }
         }
+        ST_T(const unsigned long long tb = __builtin_readcyclecounter(); if (t >= 0) tw_work += tb - ta;)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (see the loader's barrier)
+        ST_T(if (t >= 0) tw_bar += __builtin_readcyclecounter() - tb;)
     }
+#ifdef STREAM_TIMING
+    if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 100))
+        printf("stream L=%d even=%d wg %d layer %d half %d: steps %d total %llu work %llu barrier %llu cycles\n", L, (int)EVEN, (int)blockIdx.x, lw, HALF, NT,
+               __builtin_readcyclecounter() - tw0, tw_work, tw_bar);
+#endif
     if (F16 && !p.rg.gated && p.rg.flag && st.amax >= 0x47000000u) *p.rg.flag = 1u;   // a stored magnitude >= 32768 (or a NaN): the fp16 range guard
 }
 
