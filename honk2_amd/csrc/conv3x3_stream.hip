@@ -113,7 +113,6 @@ struct StreamCfg<3> {
     static constexpr int LAG = 128;       // layer l + 1 works two steps behind layer l: the step layer l is writing never meets the (Ws + 1 <= 48)-cell reach of its consumer, and every layer's steps stay 64-aligned in every ring
     static constexpr int BACK = 96;       // the first layer starts 2 x 48 positions in front of the span (the last layer needs it from S0 - 2 (Ws + 1))
     static constexpr int R0 = 384, G0 = 64;   // ring 0 (the staged input): live window = 128 (residual of layer 1) + 256 (three steps of look-ahead + the segment in flight)
-    static constexpr int R1 = 320, G1 = 48;   // rings 1, 2: live window = 256 (residual of the layer after next) + 64 (the step being written)
     static constexpr int RREC = 512;      // record ring (power of two)
 };
 template <>
@@ -122,16 +121,22 @@ struct StreamCfg<1> {
     static constexpr int LAG = 0;
     static constexpr int BACK = 0;
     static constexpr int R0 = 960, G0 = 64;   // five steps: live window = 41 (reach) + 4 S (the step being read, two of look-ahead, the segment in flight); guards of 64 cells (>= the 48-cell reach)
-    static constexpr int R1 = 0, G1 = 0;
     static constexpr int RREC = 1024;
 };
 // (the loader's DMA stream runs THREE steps in front of the first layer: segments stay aligned to the ring, the copy issued in iteration t - 2 is
 // waited for at the top of iteration t - 1 and read from step t on)
 constexpr int S_T_START = -4;             // loader iterations in front of the first compute step
 
-template <int L>
+template <int L, bool EVEN>
 struct StreamLds {
     using C = StreamCfg<L>;
+    // rings 1 and 2 hold 256 cells (live window: the 64 cells being written + two steps of lag + the consumer's 41-cell reach) unless the map is ALSO
+    // the residual of the layer after next (x_a of an even-first run: ring 1), which reads it two more steps behind: 320
+    static constexpr int R1 = L == 3 ? (EVEN ? 320 : 256) : 0, R2 = L == 3 ? 256 : 0, G1 = L == 3 ? 48 : 0;
+    // ring 3 (odd-first runs): the LAST layer's output, two steps, copied to memory by the storer wave one step behind (the compute waves then issue no
+    // memory operation at all; an even-first run has no LDS left for it and stores from its compute waves)
+    static constexpr int R3 = (L == 3 && !EVEN) ? 128 : 0;
+    static constexpr bool STORER = R3 > 0;
     static constexpr int ZERO = 0;                                   // zeros: what a dead tap reads (address 0 + the tile's immediate offset 16 k cells + 16 bytes)
     static constexpr int ZERO_BYTES = 5120;
     static constexpr int BORDER = ZERO_BYTES;                        // [L][16 classes][48] floats
@@ -139,19 +144,21 @@ struct StreamLds {
     static constexpr int REC = KOFF + 256;                           // [RREC] x {tap mask | class << 9 | valid << 13, output cell, residual cell, 0}
     static constexpr int MAP0 = REC + C::RREC * 16 + C::G0 * SC;     // byte address of slot 0 of ring 0 (its front guard lies below)
     static constexpr int MAP0_END = MAP0 + (C::R0 + C::G0) * SC;
-    static constexpr int MAP1 = MAP0_END + C::G1 * SC;
-    static constexpr int MAP1_END = MAP1 + (C::R1 + C::G1) * SC;
-    static constexpr int MAP2 = MAP1_END + C::G1 * SC;
-    static constexpr int MAP2_END = MAP2 + (C::R1 + C::G1) * SC;
+    static constexpr int MAP1 = MAP0_END + G1 * SC;
+    static constexpr int MAP1_END = MAP1 + (R1 + G1) * SC;
+    static constexpr int MAP2 = MAP1_END + G1 * SC;
+    static constexpr int MAP2_END = MAP2 + (R2 + G1) * SC;
+    static constexpr int MAP3 = MAP2_END;
+    static constexpr int MAP3_END = MAP3 + R3 * SC;
     // a first layer's residual that comes from memory: what a wave requested during the previous step is parked here at the top of the step (6 KB per
     // layer-0 wave pair: [tile][channel tile][lane] x 8 B; a single layer has three such pairs)
-    static constexpr int RSTAGE = L == 3 ? MAP2_END : MAP0_END;
+    static constexpr int RSTAGE = L == 3 ? MAP3_END : MAP0_END;
     static constexpr int RSTAGE_BYTES = 4 * 3 * 64 * 8;
-    static constexpr int BYTES = RSTAGE + (L == 3 ? 1 : 3) * RSTAGE_BYTES;
+    static constexpr int BYTES = RSTAGE + (EVEN ? (L == 3 ? 1 : 3) * RSTAGE_BYTES : 0);
 };
-static_assert(StreamLds<3>::BYTES <= 160 * 1024 - 256 && StreamLds<1>::BYTES <= 160 * 1024 - 256, "one workgroup per CU");
-static_assert(StreamCfg<3>::R0 % StreamCfg<3>::S == 0 && StreamCfg<1>::R0 % StreamCfg<1>::S == 0 && StreamCfg<3>::R1 % 64 == 0 && StreamCfg<3>::R0 % 64 == 0 && StreamCfg<1>::R0 % 64 == 0 &&
-                  StreamCfg<3>::LAG % 64 == 0 && StreamCfg<3>::BACK % 16 == 0 && 3 * 16 * SC + 16 <= StreamLds<3>::ZERO_BYTES,
+static_assert(StreamLds<3, false>::BYTES <= 160 * 1024 - 256 && StreamLds<3, true>::BYTES <= 160 * 1024 - 256 && StreamLds<1, true>::BYTES <= 160 * 1024 - 256, "one workgroup per CU");
+static_assert(StreamCfg<3>::R0 % StreamCfg<3>::S == 0 && StreamCfg<1>::R0 % StreamCfg<1>::S == 0 && StreamCfg<3>::R0 % 64 == 0 && StreamCfg<1>::R0 % 64 == 0 &&
+                  StreamCfg<3>::LAG % 64 == 0 && StreamCfg<3>::BACK % 16 == 0 && 3 * 16 * SC + 16 <= StreamLds<3, false>::ZERO_BYTES,
               "segments never wrap inside ring 0, and the four tiles of a step are consecutive slots of every ring");
 
 #define SMFH(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(s_f16x8, A_), __builtin_bit_cast(s_f16x8, B_), C_, 0, 0, 0)
@@ -162,17 +169,19 @@ static_assert(StreamCfg<3>::R0 % StreamCfg<3>::S == 0 && StreamCfg<1>::R0 % Stre
 template <bool F16, int L, bool EVEN, int ELL>
 struct StreamRole {
     using C = StreamCfg<L>;
-    using M = StreamLds<L>;
+    using M = StreamLds<L, EVEN>;
     static constexpr bool LAST = ELL == L - 1;
     static constexpr bool LAYER_EVEN = EVEN ? (ELL % 2 == 0) : (ELL % 2 == 1);     // parity of the reference's layer index a + ELL
     static constexpr int RES = !LAYER_EVEN ? 0 : (ELL == 0 ? 1 : 2);                 // residual: none / from memory (table cell) / from LDS ring ELL - 1
-    static constexpr bool OUT2 = L == 3 && !EVEN && ELL == 1;                      // x_{a+1} also goes to memory (the next run's residual)
+    static constexpr bool TO_RING = !LAST || M::STORER;                            // the output goes to an LDS ring (the next layer's input, or the storer's ring 3)
+    static constexpr bool OUT2 = L == 3 && !EVEN && ELL == 1 && !M::STORER;        // x_{a+1} also goes to memory (the next run's residual) -- from the compute waves only where there is no storer
     static constexpr int IN_ADDR = ELL == 0 ? M::MAP0 : (ELL == 1 ? M::MAP1 : M::MAP2);
-    static constexpr int IN_R = ELL == 0 ? C::R0 : C::R1;
-    static constexpr int OUT_ADDR = ELL == 0 ? M::MAP1 : M::MAP2;                   // (not LAST)
-    static constexpr int OUT_R = C::R1, OUT_G = C::G1;
+    static constexpr int IN_R = ELL == 0 ? C::R0 : (ELL == 1 ? M::R1 : M::R2);
+    static constexpr int OUT_ADDR = ELL == 0 ? M::MAP1 : (ELL == 1 ? M::MAP2 : M::MAP3);
+    static constexpr int OUT_R = ELL == 0 ? M::R1 : (ELL == 1 ? M::R2 : M::R3);
+    static constexpr int OUT_G = LAST ? 0 : M::G1;                                  // (ring 3 has no guards: nobody taps it)
     static constexpr int RES_ADDR = ELL == 1 ? M::MAP0 : M::MAP1;                   // (RES == 2: x_{i-2} is the input of layer ELL - 1)
-    static constexpr int RES_R = ELL == 1 ? C::R0 : C::R1;
+    static constexpr int RES_R = ELL == 1 ? C::R0 : M::R1;
 };
 
 // compile-time unrolled loop: f(std::integral_constant<int, i>) for i in [B, E)
@@ -213,7 +222,7 @@ template <bool F16, int L, int HALF>
 __device__ __forceinline__ void stream_request_residual(const StreamConvParams& p, StreamWaveState<StreamHalf<HALF>::NM>& st, const int p_step, const int X0,
                                                         const int need_lo, const int need_hi, const int g, const int pcol) {
     using C = StreamCfg<L>;
-    using M = StreamLds<L>;
+    using M = StreamLds<L, true>;   // (only an even-first run / an even single layer has such a residual)
     using HF = StreamHalf<HALF>;
     const char* const resp = reinterpret_cast<const char*>(p.res);
 #pragma unroll
@@ -236,12 +245,12 @@ __device__ __forceinline__ void stream_fetch_records(const StreamConvParams& p, 
                                                      const int need_lo, const int need_hi, const int pcol) {
     using R = StreamRole<F16, L, EVEN, ELL>;
     using C = StreamCfg<L>;
-    using M = StreamLds<L>;
+    using M = StreamLds<L, EVEN>;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int p0 = p_step + 16 * k;
         const int ra = M::REC + ((((p0 - X0) & (C::RREC - 1)) + pcol) << 4);
-        if (R::LAST) {
+        if (R::LAST && !R::TO_RING) {
             const su32x2 e = s_read8(ra);
             st.tmk[k] = (int)e[0];
             st.ocl[k] = (int)e[1];
@@ -265,11 +274,11 @@ __device__ __forceinline__ void stream_compute_step(const StreamConvParams& p, S
                                                     const int S1, const int need_lo, const int need_hi, const int g, const int pcol, const int lane, const int rstage) {
     using R = StreamRole<F16, L, EVEN, ELL>;
     using C = StreamCfg<L>;
-    using M = StreamLds<L>;
+    using M = StreamLds<L, EVEN>;
     using HF = StreamHalf<HALF>;
     constexpr int NM = HF::NM;
     // slots of the step's first tile in the rings: steps are 64-aligned and every ring is a multiple of 64 long, so tile k sits 16 k slots on
-    const int s_out = R::LAST ? 0 : s_mod(p_step - X0, R::OUT_R);
+    const int s_out = R::TO_RING ? s_mod(p_step - X0, R::OUT_R) : 0;
     const int s_res = R::RES == 2 ? s_mod(p_step - X0, R::RES_R) : 0;
     const float inv_scale = p.inv_scale[ELL];
     char* const outp = reinterpret_cast<char*>(p.out);
@@ -323,12 +332,12 @@ __device__ __forceinline__ void stream_compute_step(const StreamConvParams& p, S
             }
             const su32x2 pk = s_pack4<F16>(v);
             if (STREAM_ABLATE & 48) asm volatile("" ::"v"(pk));     // (experiments) 16: no stores to memory; 32: no ring writes
-            if (!R::LAST && !(STREAM_ABLATE & 32)) {
+            if (R::TO_RING && !(STREAM_ABLATE & 32)) {
                 const int oa = R::OUT_ADDR + (so + pcol) * SC + co0 * 2;
                 s_write8(oa, pk);
-                if (so < R::OUT_G) s_write8(oa + R::OUT_R * SC, pk);               // (uniform) the guard copy behind the ring
-                if (so >= R::OUT_R - R::OUT_G) s_write8(oa - R::OUT_R * SC, pk);   // (uniform) ... in front of it
-            } else if (R::LAST && own && !(STREAM_ABLATE & 16)) {
+                if (R::OUT_G > 0 && so < R::OUT_G) s_write8(oa + R::OUT_R * SC, pk);               // (uniform) the guard copy behind the ring
+                if (R::OUT_G > 0 && so >= R::OUT_R - R::OUT_G) s_write8(oa - R::OUT_R * SC, pk);   // (uniform) ... in front of it
+            } else if (!R::TO_RING && own && !(STREAM_ABLATE & 16)) {
                 *reinterpret_cast<su32x2*>(outp + (size_t)st.ocl[k] * SC + co0 * 2) = pk;
             }
             if (R::OUT2 && own && !(STREAM_ABLATE & 16)) *reinterpret_cast<su32x2*>(out2p + (size_t)pl * SC + co0 * 2) = pk;
@@ -383,7 +392,7 @@ template <bool F16, int L, bool EVEN, int ELL, int HALF>
 __device__ __forceinline__ void stream_prime(const StreamConvParams& p, StreamWaveState<StreamHalf<HALF>::NM>& st, const int p_step, const int X0, const int need_lo,
                                              const int need_hi, const int g, const int pcol) {
     using R = StreamRole<F16, L, EVEN, ELL>;
-    using M = StreamLds<L>;
+    using M = StreamLds<L, EVEN>;
     stream_fetch_records<F16, L, EVEN, ELL, HALF>(p, st, p_step, X0, need_lo, need_hi, pcol);
     const int lb = R::IN_ADDR + (s_mod(p_step - X0, R::IN_R) + pcol) * SC;
     si32x4 ko[4];
@@ -425,7 +434,7 @@ __device__ __forceinline__ void stream_compute_wave(const StreamConvParams& p, c
     }
     const int need_margin = (L - 1 - ell) * H;
     const int need_lo = max(S0 - need_margin, 0), need_hi = min(S1 + need_margin, p.total);
-    const int rstage = StreamLds<L>::RSTAGE + (L == 3 ? 0 : lw) * StreamLds<L>::RSTAGE_BYTES;   // (used by a first layer whose residual comes from memory)
+    const int rstage = StreamLds<L, EVEN>::RSTAGE + (L == 3 ? 0 : lw) * StreamLds<L, EVEN>::RSTAGE_BYTES;   // (used by a first layer whose residual comes from memory)
     const int x_wave = L == 3 ? X0 - ell * C::LAG : X0 + lw * 64;    // where this wave's stream starts (a single layer: three thirds of a 192-position step)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the workgroup's set-up barrier)
 #ifdef STREAM_TIMING   // (experiments) where a wave's time goes: cycles in its own work / at the step barrier, printed by two workgroups
@@ -472,7 +481,7 @@ __device__ __forceinline__ void stream_compute_wave(const StreamConvParams& p, c
 template <bool F16, int L, bool EVEN>
 __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamConvParams p) {
     using C = StreamCfg<L>;
-    using M = StreamLds<L>;
+    using M = StreamLds<L, EVEN>;
     extern __shared__ __align__(16) char lds[];
     if (range_gate_closed(p.rg)) return;
     if ((unsigned)reinterpret_cast<uintptr_t>(lds) != 0u) __builtin_trap();   // LDS is addressed through absolute 32-bit integers
@@ -515,8 +524,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamConvParams
         recpos[j] = 0;
     }
     bool have_rec = false;
+    // the storer (wave 7, odd-first runs of three): one step behind the layers, it copies what they finished to memory as whole 16-byte pieces of
+    // whole 96-byte cells -- x_{a+1} out of ring 2 (the next run's residual, in the input's own layout) and the last layer's output out of ring 3
+    // (cells of the consumer's layout, from the records).  The compute waves' 8-byte stores were store-ISSUE bound (-15 % without them).
+    auto store_step = [&](int tprev) {
+        if (!M::STORER || tprev < 0) return;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int P = X0 - (which == 0 ? 1 : 2) * C::LAG + tprev * C::S;       // what layer 1 / layer 2 covered in step tprev
+            if (P + C::S <= S0 || P >= S1) continue;                                 // (uniform) nothing of this workgroup's own span
+            const int slot = s_mod(P - X0, which == 0 ? M::R2 : (M::R3 > 0 ? M::R3 : 1));
+            const int ring = which == 0 ? M::MAP2 : M::MAP3;
+            char* const dstp = reinterpret_cast<char*>(which == 0 ? p.out2 : p.out);
+#pragma unroll
+            for (int i = 0; i < C::S * 6 / 64; ++i) {
+                const int c = i * 64 + lane;
+                const int cell = c / 6, qd = c - cell * 6;
+                const int pos = P + cell;
+                const su32x2 e = s_read8(M::REC + (((pos - X0) & (C::RREC - 1)) << 4));      // {tap mask word, output cell}
+                const su32x4 v = *reinterpret_cast<s_lds_u32x4_cptr>((unsigned)(ring + (slot + cell) * SC + qd * 16));
+                const bool live = pos >= S0 && pos < S1 && ((e[0] >> 13) & 1);
+                const size_t dcell = which == 0 ? (size_t)pos : (size_t)e[1];
+                if (live) *reinterpret_cast<su32x4*>(dstp + dcell * SC + qd * 16) = v;
+            }
+        }
+    };
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the workgroup's set-up barrier)
     for (int t = S_T_START; t < NT; ++t) {
+        if (half == 1) store_step(t - 1);
         if (half == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // what the previous iteration requested has landed (LDS ring 0) / arrived (records)
             if (have_rec) {
@@ -562,6 +597,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamConvParams
         // step, the loader's copies for the step after next.  The loader waits for its own copies itself, one iteration after issuing them.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    if (half == 1) store_step(NT - 1);          // what the layers wrote in the last step (visible behind the last barrier)
 }
 
 bool conv3x3_stream_supported(int C, int Ws) { return (C + 7) / 8 * 8 == 48 && Ws >= 1 && Ws + 1 <= 48; }
@@ -574,7 +610,8 @@ static hipError_t launch_stream_k(const StreamConvParams& p, unsigned grid, hipS
         hipError_t e = allow_big_lds_at_base_zero(reinterpret_cast<const void*>(k));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), StreamLds<L>::BYTES, s, p);
+    constexpr size_t lds_bytes = StreamLds<L, EVEN>::BYTES;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds_bytes, s, p);
     return hipGetLastError();
 }
 
