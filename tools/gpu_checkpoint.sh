@@ -19,4 +19,4 @@ timeout -k 10 600 python tools/bench_models.py > gpurun_out/${tag}_models.jsonl 
 KWS_BENCH_DTYPE=bf16 KWS_BENCH_BATCH=4096 timeout -k 10 300 python tools/bench_models.py resnet__res15 >> gpurun_out/${tag}_models.jsonl 2>/dev/null || exit 1
 KWS_BENCH_DTYPE=fp16 KWS_BENCH_BATCH=8192 timeout -k 10 300 python tools/bench_models.py cnn__cnn-trad-pool2 >> gpurun_out/${tag}_models.jsonl 2>/dev/null || exit 1
 cut -c1-175 gpurun_out/${tag}_models.jsonl
-bash tools/profile_round.sh $tag
+bash tools/profile_round.sh $tag r05
