@@ -150,13 +150,13 @@ struct StreamLds {
     static constexpr int MAP2_END = MAP2 + (R2 + G1) * SC;
     static constexpr int MAP3 = MAP2_END;
     static constexpr int MAP3_END = MAP3 + R3 * SC;
-    // a first layer's residual that comes from memory: what a wave requested during the previous step is parked here at the top of the step (6 KB per
-    // layer-0 wave pair: [tile][channel tile][lane] x 8 B; a single layer has three such pairs)
-    static constexpr int RSTAGE = L == 3 ? MAP3_END : MAP0_END;
-    static constexpr int RSTAGE_BYTES = 4 * 3 * 64 * 8;
-    static constexpr int BYTES = RSTAGE + (EVEN ? (L == 3 ? 1 : 3) * RSTAGE_BYTES : 0);
+    // an even-first run's first layer takes its residual x_{a-2} from memory: the LOADER fetches those cells (through the records' residual cell) and
+    // parks them here, two steps of 64 cells by step parity, so that the compute waves read it like any other ring
+    static constexpr int RSTAGE = MAP3_END;
+    static constexpr int RSTAGE_STEP = 64 * SC;
+    static constexpr int BYTES = RSTAGE + ((L == 3 && EVEN) ? 2 * RSTAGE_STEP : 0);
 };
-static_assert(StreamLds<3, false>::BYTES <= 160 * 1024 - 256 && StreamLds<3, true>::BYTES <= 160 * 1024 - 256 && StreamLds<1, true>::BYTES <= 160 * 1024 - 256, "one workgroup per CU");
+static_assert(StreamLds<3, false>::BYTES <= 160 * 1024 - 256 && StreamLds<3, true>::BYTES <= 160 * 1024 - 256 && StreamLds<1, false>::BYTES <= 160 * 1024 - 256, "one workgroup per CU");
 static_assert(StreamCfg<3>::R0 % StreamCfg<3>::S == 0 && StreamCfg<1>::R0 % StreamCfg<1>::S == 0 && StreamCfg<3>::R0 % 64 == 0 && StreamCfg<1>::R0 % 64 == 0 &&
                   StreamCfg<3>::LAG % 64 == 0 && StreamCfg<3>::BACK % 16 == 0 && 3 * 16 * SC + 16 <= StreamLds<3, false>::ZERO_BYTES,
               "segments never wrap inside ring 0, and the four tiles of a step are consecutive slots of every ring");
@@ -209,35 +209,8 @@ struct StreamWaveState {     // what a compute wave keeps across steps (register
     int ktap[5];                // taps of the five k-steps whose lane groups straddle two taps (s = 1, 4, 7, 10, 13)
     int base[S_STEPS];          // LDS address of tile 0's B fragment of k-step s in the CURRENT step (advanced by 64 cells per step)
     int tmk[4], ocl[4];         // the current step's records: tap mask | border class << 9 | valid << 13, output cell (read at the end of the step before)
-    su32x2 res_next[4][NM];   // a residual that comes from memory: requested one step ahead (the step before consumes what this one requested)
     unsigned amax;
 };
-
-// A first layer's residual x_{a-2} comes from memory.  Per step: (1) what the previous step requested is parked in the wave's own LDS staging block
-// -- hipcc guards a loop-carried load with `s_waitcnt vmcnt(0)`, which is free exactly here, where the wave's youngest memory operation is a step
-// old; (2) the next step's residual is requested (its records are in the ring already) and has the whole step to arrive; (3) the epilogues read the
-// parked values.  (Requested and consumed inside one step, or consumed behind younger requests, the wait is a memory round trip per tile: measured
-// 1.56 against 0.85 ms per run.)
-template <bool F16, int L, int HALF>
-__device__ __forceinline__ void stream_request_residual(const StreamConvParams& p, StreamWaveState<StreamHalf<HALF>::NM>& st, const int p_step, const int X0,
-                                                        const int need_lo, const int need_hi, const int g, const int pcol) {
-    using C = StreamCfg<L>;
-    using M = StreamLds<L, true>;   // (only an even-first run / an even single layer has such a residual)
-    using HF = StreamHalf<HALF>;
-    const char* const resp = reinterpret_cast<const char*>(p.res);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int p0 = p_step + 16 * k;
-        const bool skip = p0 + 16 <= need_lo || p0 >= need_hi;        // (uniform)
-        const si32x4 rc = *reinterpret_cast<s_lds_i32x4_cptr>((unsigned)(M::REC + ((((p0 - X0) & (C::RREC - 1)) + pcol) << 4)));
-        const bool live = !skip && (unsigned)(p0 + pcol) < (unsigned)p.total && ((rc[0] >> 13) & 1);
-#pragma unroll
-        for (int m = 0; m < HF::NM; ++m) {
-            st.res_next[k][m] = (su32x2){0u, 0u};
-            if (live) st.res_next[k][m] = *reinterpret_cast<const su32x2*>(resp + (size_t)rc[2] * SC + ((HF::M0 + m) * 16 + 4 * g) * 2);
-        }
-    }
-}
 
 // records of the step that starts at p_step into the wave state (tap-mask word, output cell) -- read one step ahead, at the END of the step before
 template <bool F16, int L, bool EVEN, int ELL, int HALF>
@@ -271,7 +244,7 @@ __device__ __forceinline__ void stream_fetch_records(const StreamConvParams& p, 
 // drains the matrix pipe for an epilogue nor waits on an LDS round trip inside one.
 template <bool F16, int L, bool EVEN, int ELL, int HALF>
 __device__ __forceinline__ void stream_compute_step(const StreamConvParams& p, StreamWaveState<StreamHalf<HALF>::NM>& st, const int p_step, const int X0, const int S0,
-                                                    const int S1, const int need_lo, const int need_hi, const int g, const int pcol, const int lane, const int rstage) {
+                                                    const int S1, const int need_lo, const int need_hi, const int g, const int pcol, const int tstep) {
     using R = StreamRole<F16, L, EVEN, ELL>;
     using C = StreamCfg<L>;
     using M = StreamLds<L, EVEN>;
@@ -284,13 +257,6 @@ __device__ __forceinline__ void stream_compute_step(const StreamConvParams& p, S
     char* const outp = reinterpret_cast<char*>(p.out);
     char* const out2p = reinterpret_cast<char*>(p.out2);
 
-    if (R::RES == 1) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int m = 0; m < NM; ++m) s_write8(rstage + ((k * 3 + HF::M0 + m) * 64 + lane) * 8, st.res_next[k][m]);
-        stream_request_residual<F16, L, HALF>(p, st, p_step + C::S, X0, need_lo, need_hi, g, pcol);
-    }
     // B fragments: st.base[s] is the address of tile 0's fragment of k-step s; tile k adds 16 k cells as the read's immediate offset.  A dead tap's
     // address is 0 -- the zero region at the bottom of LDS is long enough for the four immediates.  A ring of NBUF registers runs over the step's
     // 4 x 14 (tile, k-step) sequence: fragment i + NBUF is requested right behind the MFMAs that consume fragment i.
@@ -351,7 +317,7 @@ __device__ __forceinline__ void stream_compute_step(const StreamConvParams& p, S
         for (int m = 0; m < NM; ++m) {
             const int co0 = (HF::M0 + m) * 16 + 4 * g;
             ebb[m] = *reinterpret_cast<s_lds_f32x4_cptr>((unsigned)(M::BORDER + ((ELL * 16 + bmask) * 48 + co0) * 4));
-            if (R::RES == 1) erv[m] = s_read8(rstage + ((k * 3 + HF::M0 + m) * 64 + lane) * 8);   // (parked at the top of the step)
+            if (R::RES == 1) erv[m] = s_read8(M::RSTAGE + (tstep & 1) * M::RSTAGE_STEP + (16 * k + pcol) * SC + co0 * 2);   // (parked by the loader, by step parity)
             if (R::RES == 2) erv[m] = s_read8(R::RES_ADDR + (s_res + 16 * k + pcol) * SC + co0 * 2);
         }
     };
@@ -434,7 +400,6 @@ __device__ __forceinline__ void stream_compute_wave(const StreamConvParams& p, c
     }
     const int need_margin = (L - 1 - ell) * H;
     const int need_lo = max(S0 - need_margin, 0), need_hi = min(S1 + need_margin, p.total);
-    const int rstage = StreamLds<L, EVEN>::RSTAGE + (L == 3 ? 0 : lw) * StreamLds<L, EVEN>::RSTAGE_BYTES;   // (used by a first layer whose residual comes from memory)
     const int x_wave = L == 3 ? X0 - ell * C::LAG : X0 + lw * 64;    // where this wave's stream starts (a single layer: three thirds of a 192-position step)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the workgroup's set-up barrier)
 #ifdef STREAM_TIMING   // (experiments) where a wave's time goes: cycles in its own work / at the step barrier, printed by two workgroups
@@ -446,8 +411,7 @@ __device__ __forceinline__ void stream_compute_wave(const StreamConvParams& p, c
     for (int t = S_T_START; t < NT; ++t) {
         ST_T(const unsigned long long ta = __builtin_readcyclecounter();)
         if (t == -1) {
-            // step 0's records and fragment addresses; a first layer whose residual comes from memory requests step 0's (layer 0 of an even-first run /
-            // an even single layer)
+            // step 0's records and fragment addresses
             if (L == 3) {
                 if (ell == 0) stream_prime<F16, L, EVEN, 0, HALF>(p, st, x_wave, X0, need_lo, need_hi, g, pcol);
                 else if (ell == 1) stream_prime<F16, L, EVEN, L == 3 ? 1 : 0, HALF>(p, st, x_wave, X0, need_lo, need_hi, g, pcol);
@@ -455,15 +419,14 @@ __device__ __forceinline__ void stream_compute_wave(const StreamConvParams& p, c
             } else {
                 stream_prime<F16, L, EVEN, 0, HALF>(p, st, x_wave, X0, need_lo, need_hi, g, pcol);
             }
-            if (EVEN && ell == 0) stream_request_residual<F16, L, HALF>(p, st, x_wave, X0, need_lo, need_hi, g, pcol);
         } else if (t >= 0) {
             const int p_step = x_wave + t * C::S;
             if (L == 3) {
-                if (ell == 0) stream_compute_step<F16, L, EVEN, 0, HALF>(p, st, p_step, X0, S0, S1, need_lo, need_hi, g, pcol, lane, rstage);
-                else if (ell == 1) stream_compute_step<F16, L, EVEN, L == 3 ? 1 : 0, HALF>(p, st, p_step, X0, S0, S1, need_lo, need_hi, g, pcol, lane, rstage);
-                else stream_compute_step<F16, L, EVEN, L == 3 ? 2 : 0, HALF>(p, st, p_step, X0, S0, S1, need_lo, need_hi, g, pcol, lane, rstage);
+                if (ell == 0) stream_compute_step<F16, L, EVEN, 0, HALF>(p, st, p_step, X0, S0, S1, need_lo, need_hi, g, pcol, t);
+                else if (ell == 1) stream_compute_step<F16, L, EVEN, L == 3 ? 1 : 0, HALF>(p, st, p_step, X0, S0, S1, need_lo, need_hi, g, pcol, t);
+                else stream_compute_step<F16, L, EVEN, L == 3 ? 2 : 0, HALF>(p, st, p_step, X0, S0, S1, need_lo, need_hi, g, pcol, t);
             } else {
-                stream_compute_step<F16, L, EVEN, 0, HALF>(p, st, p_step, X0, S0, S1, need_lo, need_hi, g, pcol, lane, rstage);
+                stream_compute_step<F16, L, EVEN, 0, HALF>(p, st, p_step, X0, S0, S1, need_lo, need_hi, g, pcol, t);
             }
         }
         ST_T(const unsigned long long tb = __builtin_readcyclecounter(); if (t >= 0) tw_work += tb - ta;)
@@ -523,7 +486,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamConvParams
         recv[j] = (si32x4){0, 0, 0, 0};
         recpos[j] = 0;
     }
-    bool have_rec = false;
+    bool have_rec = false, have_res = false;
+    su32x4 resv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) resv[i] = (su32x4){0u, 0u, 0u, 0u};
     // the storer (wave 7, odd-first runs of three): one step behind the layers, it copies what they finished to memory as whole 16-byte pieces of
     // whole 96-byte cells -- x_{a+1} out of ring 2 (the next run's residual, in the input's own layout) and the last layer's output out of ring 3
     // (cells of the consumer's layout, from the records).  The compute waves' 8-byte stores were store-ISSUE bound (-15 % without them).
@@ -558,6 +524,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_stream_kernel(StreamConvParams
 #pragma unroll
                 for (int j = 0; j < NREC; ++j)
                     *reinterpret_cast<s_lds_i32x4_ptr>((unsigned)(M::REC + (((recpos[j] - X0) & (C::RREC - 1)) << 4))) = recv[j];
+            }
+            if (L == 3 && EVEN) {
+                // the first layer's residual x_{a-2}: what the previous iteration fetched is parked for step t + 1 (by step parity); then the cells of step
+                // t + 2 -- whose records this wave has just written -- are fetched through the records' residual cell: whole 96-byte cells, 16 bytes per lane
+                if (have_res) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i)
+                        *reinterpret_cast<s_lds_u32x4_ptr>((unsigned)(M::RSTAGE + ((t + 1) & 1) * M::RSTAGE_STEP + (i * 64 + lane) * 16)) = resv[i];
+                }
+                have_res = t + 2 >= 0;
+                if (have_res) {
+                    const char* const resp = reinterpret_cast<const char*>(p.res);
+                    const int PR = X0 + (t + 2) * C::S;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const int c = i * 64 + lane;
+                        const int cell = c / 6, qd = c - cell * 6;
+                        const int pos = PR + cell;
+                        const si32x4 e = *reinterpret_cast<s_lds_i32x4_cptr>((unsigned)(M::REC + (((pos - X0) & (C::RREC - 1)) << 4)));
+                        resv[i] = (su32x4){0u, 0u, 0u, 0u};
+                        if ((unsigned)pos < (unsigned)p.total && ((e[0] >> 13) & 1)) resv[i] = *reinterpret_cast<const su32x4*>(resp + (size_t)e[2] * SC + qd * 16);
+                    }
+                }
             }
             // ring 0: cells [PD, PD + S) of the input tensor, a flat copy (cells outside the tensor are clamped: they are never tapped)
             const int PD = X0 + (t + 3) * C::S;
@@ -634,8 +623,8 @@ hipError_t launch_conv3x3_stream(const StreamConvParams& p_in, int C, int n_cu, 
         if (p.f16) return even ? launch_stream_k<true, 3, true>(p, grid, s) : launch_stream_k<true, 3, false>(p, grid, s);
         return even ? launch_stream_k<false, 3, true>(p, grid, s) : launch_stream_k<false, 3, false>(p, grid, s);
     }
-    if (p.f16) return even ? launch_stream_k<true, 1, true>(p, grid, s) : launch_stream_k<true, 1, false>(p, grid, s);
-    return even ? launch_stream_k<false, 1, true>(p, grid, s) : launch_stream_k<false, 1, false>(p, grid, s);
+    if (even) return hipErrorInvalidValue;     // (an even single layer takes its residual from memory: the tile kernel's job)
+    return p.f16 ? launch_stream_k<true, 1, false>(p, grid, s) : launch_stream_k<false, 1, false>(p, grid, s);
 }
 
 }  // namespace kws

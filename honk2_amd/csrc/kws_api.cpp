@@ -173,7 +173,7 @@ struct kws_handle {
     bool lin_in_f16 = true;                // cnn band plan, `fp16` dtype: fp16 cells between conv_1 and the first Linear (KWS_CNN_LIN_F16=0: fp32 cells, A/B and tests)
     int t3_triple = 1;                     // runs of three equal-dilation layers in one kernel (KWS_T3_TRIPLE=0: pairs + singles; 2: any three consecutive layers)
     bool t3_pair = true;                   // tiled plan, 16-bit tensors: consecutive layers of equal dilation in one kernel (KWS_T3_PAIR=0: off)
-    int t3_stream = 1;                     // tiled plan, 16-bit tensors, 41-48 channels: odd-first runs of three layers and odd single layers as persistent weight-stationary streams (conv3x3_stream.hip; KWS_T3_STREAM=0: the tile kernels only; 2: even-first runs / even singles too)
+    int t3_stream = 1;                     // tiled plan, 16-bit tensors, 41-48 channels: runs of three layers and odd single layers as persistent weight-stationary streams (conv3x3_stream.hip; KWS_T3_STREAM=0: the tile kernels only; 3: odd-first runs only)
     DevMem r8_shift;                       // fused res8, kws_forward: per-clip power-of-two shifts of caller-provided features (feat_shift_kernel)
     std::vector<void*> parked;             // outgrown r8_shift blocks: a captured graph may still name them, so they live as long as the handle
     DevMem range_flag;                     // device words: [0] fp16 range guard of the layer-wise plans (kws_internal.h), [16] /
@@ -793,9 +793,8 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                 // (t3_triple == 2, A/B runs: any three consecutive layers of one dilation)
                 const int Hs_i = (sh.H + dd - 1) / dd, Ws_i = (sh.W + dd - 1) / dd;
                 // (r5) any three consecutive layers of one dilation as ONE persistent weight-stationary stream (conv3x3_stream.hip); bit-identical to the forms below
-                // (measured, res15 `bf16`, 1 024 clips: an odd-first run 0.675 ms as a stream against 0.73 as a triple / 0.80 as pair + single; an even-first run,
-                // whose first layer takes its residual from memory, 1.13 against 0.70 - 0.79: the default streams odd-first runs only; t3_stream == 2: every run)
-                if (m_terms == 1 && h->t3_stream && (!even || h->t3_stream == 2) && i + 2 <= d.n_layers && resnet_dilation(d, i + 1) == dd &&
+                // (measured, res15 `bf16`, B = 4 096, one machine: every run a stream 12.54 ms, odd-first runs only 13.23, tile kernels only 14.03; t3_stream == 3: odd-first runs only)
+                if (m_terms == 1 && h->t3_stream && (!even || h->t3_stream != 3) && i + 2 <= d.n_layers && resnet_dilation(d, i + 1) == dd &&
                     resnet_dilation(d, i + 2) == dd && conv3x3_stream_supported(C, Ws_i)) {
                     const int ld_out3 = i + 2 < d.n_layers ? ilog2(resnet_dilation(d, i + 3)) : 0;
                     std::unique_ptr<ConvLayer::PosTab>& pt3 = h->rconv[i].postabs3[T];
@@ -966,7 +965,7 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                     if ((rc = t3_buf.upload(z.data(), z.size() * 8))) return rc;
                     tp.dbg_ts = t3_buf.as<unsigned long long>();
                 }
-                const bool stream1 = m_terms == 1 && h->t3_stream && (!even || h->t3_stream == 2) && !t3_this && conv3x3_stream_supported(C, tp.Ws);
+                const bool stream1 = m_terms == 1 && h->t3_stream && !even && !t3_this && conv3x3_stream_supported(C, tp.Ws);   // (an even single layer takes its residual from memory: the tile kernel)
                 if (stream1) {   // (r5) a single layer as a persistent weight-stationary stream: the same tensors, table and bits
                     StreamConvParams sp{};
                     sp.first_even = even ? 1 : 0;
@@ -1372,7 +1371,7 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
     if (const char* tp = std::getenv("KWS_T3_TRIPLE")) h->t3_triple = std::atoi(tp);
     if (const char* tp = std::getenv("KWS_CNN_LIN_F16")) h->lin_in_f16 = std::atoi(tp) != 0;
     if (const char* tp = std::getenv("KWS_T3_PAIR")) h->t3_pair = std::atoi(tp) != 0;   // A/B and tests: 0 = one kernel per layer
-    if (const char* tp = std::getenv("KWS_T3_STREAM")) h->t3_stream = std::atoi(tp);   // A/B and tests: 0 = tile / pair / triple kernels only, 2 = stream every run
+    if (const char* tp = std::getenv("KWS_T3_STREAM")) h->t3_stream = std::atoi(tp);   // A/B and tests: 0 = tile / pair / triple kernels only, 3 = stream odd-first runs only
     int rc = setup_frontend(h.get());
     if (rc) return rc;
     const unsigned zero_word[64] = {0};
