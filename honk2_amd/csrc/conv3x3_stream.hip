@@ -232,9 +232,11 @@ __device__ __forceinline__ void stream_fetch_records(const StreamConvParams& p, 
             st.ocl[k] = 0;
         }
         const int pl = p0 + pcol;
-        // outside the tensor, or a tile nobody needs from this layer (only at the two ends of a span): no live tap, no epilogue -- the tile still
-        // runs its MFMAs on zeros, so the k-loop has no run-time branch
-        if (!((unsigned)pl < (unsigned)p.total) || p0 + 16 <= need_lo || p0 >= need_hi) st.tmk[k] = 0;
+        // outside the tensor, or a position nobody needs from this layer (only at the two ends of a span): no live tap, no epilogue -- the tile still
+        // runs its MFMAs on zeros, so the k-loop has no run-time branch.  Per POSITION, not per tile: in a tile that straddles the end of what is needed
+        // the positions beyond it would be computed from ring cells nobody wrote -- harmless for the results, but their garbage reached the fp16
+        // range guard's maximum (found on res26 `fp16` at 4 096 clips: a spurious second pass, 18.5 ms instead of 5.6)
+        if (!((unsigned)pl < (unsigned)p.total) || pl < need_lo || pl >= need_hi) st.tmk[k] = 0;
     }
 }
 

@@ -173,7 +173,7 @@ struct kws_handle {
     bool lin_in_f16 = true;                // cnn band plan, `fp16` dtype: fp16 cells between conv_1 and the first Linear (KWS_CNN_LIN_F16=0: fp32 cells, A/B and tests)
     int t3_triple = 1;                     // runs of three equal-dilation layers in one kernel (KWS_T3_TRIPLE=0: pairs + singles; 2: any three consecutive layers)
     bool t3_pair = true;                   // tiled plan, 16-bit tensors: consecutive layers of equal dilation in one kernel (KWS_T3_PAIR=0: off)
-    int t3_stream = 1;                     // tiled plan, 16-bit tensors, 41-48 channels: runs of three layers and odd single layers as persistent weight-stationary streams (conv3x3_stream.hip; KWS_T3_STREAM=0: the tile kernels only; 3: odd-first runs only)
+    int t3_stream = 1;                     // tiled plan, 16-bit tensors, 41-48 channels: runs of three layers and odd single layers as persistent weight-stationary streams (conv3x3_stream.hip; launches of >= 7 680 cells per CU; KWS_T3_STREAM=0: the tile kernels only; 2: launches of any size; 3: odd-first runs only)
     DevMem r8_shift;                       // fused res8, kws_forward: per-clip power-of-two shifts of caller-provided features (feat_shift_kernel)
     std::vector<void*> parked;             // outgrown r8_shift blocks: a captured graph may still name them, so they live as long as the handle
     DevMem range_flag;                     // device words: [0] fp16 range guard of the layer-wise plans (kws_internal.h), [16] /
@@ -653,7 +653,17 @@ size_t resnet_cl_cells(const kws_handle* h, const ResnetShape& s) {
 int chunk_clips(size_t per_clip_elems, int B);
 int tiled_chunk(const kws_handle* h, const ResnetShape& s, int B) {
     const size_t cells = resnet_cl_cells(h, s);
-    const int cb = chunk_clips(std::max((size_t)s.C * s.T * s.F, cells * pad8(s.C)), B);
+    // (r5) a chunk is sized by its CELLS, not its clips: ~5.5 M cells of the widest layout (1 024 clips of res15's 101 x 40 map, 4 096 of res26's pooled 50 x 20 one), every
+    // tensor under 1 GiB.  The stream kernels give each CU one contiguous span of a launch's cells and pay ~11 steps of pipeline fill per span: at 1 024
+    // res26 clips a span was 62 steps long (stream 6.35 ms against 5.80 for the pair kernels at B = 4 096), at 4 096 it is 250.
+    // (Only where streams can run -- the 16-bit dtypes, 41 - 48 channels; every other plan keeps chunks of <= 1 024 clips, the unit the fp16 range guard
+    // recomputes.)
+    int cb = chunk_clips(std::max((size_t)s.C * s.T * s.F, cells * pad8(s.C)), B);
+    if ((h->d.dtype == KWS_DTYPE_BF16 || h->d.dtype == KWS_DTYPE_F16) && h->t3_stream && pad8(s.C) == 48) {
+        size_t cbs = std::max<size_t>(1, std::min<size_t>((size_t)1024 * 5376 / cells, 4096));   // (5 376 = res15's cells at dilation 16, padded sub-maps included: its chunks stay 1 024 clips)
+        cbs = std::min(cbs, ((size_t)1 << 28) / std::max<size_t>(cells * pad8(s.C), 1));
+        cb = (int)std::max<size_t>(1, std::min<size_t>(cbs, (size_t)std::max(B, 1)));
+    }
     size_t cap = (((size_t)1 << 24) - 4096) / cells;
     static const int env_cap = experiment_int("KWS_TILED_CHUNK", 0);
     if (env_cap > 0) cap = std::min<size_t>(cap, env_cap);
@@ -794,7 +804,10 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                 const int Hs_i = (sh.H + dd - 1) / dd, Ws_i = (sh.W + dd - 1) / dd;
                 // (r5) any three consecutive layers of one dilation as ONE persistent weight-stationary stream (conv3x3_stream.hip); bit-identical to the forms below
                 // (measured, res15 `bf16`, B = 4 096, one machine: every run a stream 12.54 ms, odd-first runs only 13.23, tile kernels only 14.03; t3_stream == 3: odd-first runs only)
-                if (m_terms == 1 && h->t3_stream && (!even || h->t3_stream != 3) && i + 2 <= d.n_layers && resnet_dilation(d, i + 1) == dd &&
+                // A stream gives every CU one span of the launch's cells and pays ~11 steps of 64 cells of pipeline fill per span: below ~7 700 cells per CU
+                // the tile kernels win (res26, 1.02 M cells per 1 024 clips: 1.90 against 1.76 ms; 2 048 clips: 3.40 / 3.36; 4 096: 6.05 / 6.12); t3_stream == 2: any size (tests)
+                const bool stream_size = h->t3_stream == 2 || (long long)nb * dd * dd * Hs_i * Ws_i >= 7680LL * h->n_cu;
+                if (m_terms == 1 && h->t3_stream && stream_size && (!even || h->t3_stream != 3) && i + 2 <= d.n_layers && resnet_dilation(d, i + 1) == dd &&
                     resnet_dilation(d, i + 2) == dd && conv3x3_stream_supported(C, Ws_i)) {
                     const int ld_out3 = i + 2 < d.n_layers ? ilog2(resnet_dilation(d, i + 3)) : 0;
                     std::unique_ptr<ConvLayer::PosTab>& pt3 = h->rconv[i].postabs3[T];
@@ -965,7 +978,7 @@ int run_resnet_tiled(kws_handle* h, const float* feat, int B, int T, float* logi
                     if ((rc = t3_buf.upload(z.data(), z.size() * 8))) return rc;
                     tp.dbg_ts = t3_buf.as<unsigned long long>();
                 }
-                const bool stream1 = m_terms == 1 && h->t3_stream && !even && !t3_this && conv3x3_stream_supported(C, tp.Ws);   // (an even single layer takes its residual from memory: the tile kernel)
+                const bool stream1 = m_terms == 1 && h->t3_stream && (h->t3_stream == 2 || (long long)tp.total >= 7680LL * h->n_cu) && !even && !t3_this && conv3x3_stream_supported(C, tp.Ws);   // (an even single layer takes its residual from memory: the tile kernel)
                 if (stream1) {   // (r5) a single layer as a persistent weight-stationary stream: the same tensors, table and bits
                     StreamConvParams sp{};
                     sp.first_even = even ? 1 : 0;
@@ -1371,7 +1384,7 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
     if (const char* tp = std::getenv("KWS_T3_TRIPLE")) h->t3_triple = std::atoi(tp);
     if (const char* tp = std::getenv("KWS_CNN_LIN_F16")) h->lin_in_f16 = std::atoi(tp) != 0;
     if (const char* tp = std::getenv("KWS_T3_PAIR")) h->t3_pair = std::atoi(tp) != 0;   // A/B and tests: 0 = one kernel per layer
-    if (const char* tp = std::getenv("KWS_T3_STREAM")) h->t3_stream = std::atoi(tp);   // A/B and tests: 0 = tile / pair / triple kernels only, 3 = stream odd-first runs only
+    if (const char* tp = std::getenv("KWS_T3_STREAM")) h->t3_stream = std::atoi(tp);   // A/B and tests: 0 = tile / pair / triple kernels only, 2 = streams whatever the launch size, 3 = stream odd-first runs only
     int rc = setup_frontend(h.get());
     if (rc) return rc;
     const unsigned zero_word[64] = {0};

@@ -21,7 +21,7 @@ for nl, dil, n, t in ((1, False, 2, 101), (2, False, 2, 101), (3, False, 2, 101)
     cfg = {"n_feature_maps": 45, "n_layers": nl, "use_dilation": dil, "n_labels": 12, "dtype": dtype}
     sd = weights.make_state_dict("ResNet", {k: v for k, v in cfg.items() if k != "dtype"}, seed=11)
     x = torch.from_numpy(weights.make_features(n, seed=12, time=t)).cuda()
-    os.environ["KWS_T3_STREAM"] = "1"
+    os.environ["KWS_T3_STREAM"] = "2"
     a = build(cfg, sd); ya = a(x); pa = a.plan_detail()
     os.environ["KWS_T3_STREAM"] = "0"; os.environ["KWS_T3_PAIR"] = "0"
     b = build(cfg, sd); yb = b(x)
