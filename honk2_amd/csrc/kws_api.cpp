@@ -103,6 +103,7 @@ struct ConvLayer {          // one conv (or Linear run as a 1 x K conv) of the l
     float t3h_scale = 1.f;   // 2^S of apk_t3h   // border_pad: rows padded to a multiple of 8 channels (tiled kernel)
     bool has_bias = false, has_border = false, use_x = false;   // use_x: bf16x6 kernel available for this layer
     DevMem apk_band;         // conv_band.hip fragments of a cnn-* conv_1 (fp16 parts x band_scale)
+    DevMem apk_cols;         // conv_cols.hip fragments of the same layer (`fp16` dtype, where that kernel fits)
     float band_scale = 1.f;
     DevMem apk_in1[2];       // conv_in1.hip fragments of a cnn-* conv_0 for IN1_MH3 / IN1_MH1 channel tiles per pass (x x_scale)
     std::vector<float> w_host;   // ResNet: raw weights kept until finalize() folds the previous BatchNorm in
@@ -160,6 +161,7 @@ struct kws_handle {
     bool cnn_in1 = false;                  // conv_0 runs in conv_in1.hip (LDS image of the clip) in the channels-last plans
     bool cnn_cl1 = false;                  // single-conv model: conv_in1 -> clin0_cl ("cnn_in1" plan)
     int cl_last[3] = {0, 0, 0};            // (channels, positions, channels per cell) of the tensor the first Linear reads
+    bool cnn_cols = false;                 // `fp16` dtype: conv_1 runs in conv_cols.hip (column tiles, persistent, double-buffered) instead of conv_band.hip (KWS_CNN_COLS=0: off)
     BandPlan cnn_band;                     // conv_band_plan of conv_1
     DevMem cnn_band_tab;                   // its position table
     int cnn_cp[2] = {0, 0};                // channels per cell of conv_0's / conv_1's output (padded to 16)
@@ -176,8 +178,13 @@ struct kws_handle {
     int t3_stream = 1;                     // tiled plan, 16-bit tensors, 41-48 channels: runs of three layers and odd single layers as persistent weight-stationary streams (conv3x3_stream.hip; launches of >= 7 680 cells per CU; KWS_T3_STREAM=0: the tile kernels only; 2: launches of any size; 3: odd-first runs only)
     DevMem r8_shift;                       // fused res8, kws_forward: per-clip power-of-two shifts of caller-provided features (feat_shift_kernel)
     std::vector<void*> parked;             // outgrown r8_shift blocks: a captured graph may still name them, so they live as long as the handle
-    DevMem range_flag;                     // device words: [0] fp16 range guard of the layer-wise plans (kws_internal.h), [16] /
-                                           // [32] clip / unit counters of the fused res8 and front-end kernels
+    DevMem range_flag;                     // device words: [0] (and [1]: odd chunks of the two-stream cnn plan) fp16 range guard of the layer-wise plans
+                                           // (kws_internal.h), [16] / [32] clip / unit counters of the fused res8 and front-end kernels
+    // cnn plans, calls of more than one chunk: a chunk's Linears, split-K reduces and gated second pass run on a stream of the handle while the caller's
+    // stream goes on with the next chunk's convolutions (run_cnn; KWS_CNN_STREAMS=0: everything on the caller's stream)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+    bool cnn_streams = true;
 
     // profiling
     bool prof = false;
@@ -191,6 +198,11 @@ struct kws_handle {
     ~kws_handle() {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         for (void* q : parked) (void)hipFree(q);
+        for (int i = 0; i < 2; ++i) {
+            if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
+            if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+        }
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -416,6 +428,8 @@ int build_cnn(kws_handle* h) {
             h->clin0_cl.has_bias = true;
             mx = std::max(mx, std::max((size_t)H1 * W1 * h->cnn_cp[0], (size_t)kcl));
             h->cl_last[0] = C1; h->cl_last[1] = g1.Ho * g1.Wo; h->cl_last[2] = h->cnn_cp[1];
+            const bool cols_off = std::getenv("KWS_CNN_COLS") && std::atoi(std::getenv("KWS_CNN_COLS")) == 0;   // A/B and tests
+            h->cnn_cols = !cols_off && d.dtype == KWS_DTYPE_F16 && conv_cols_supported(C0, C1, H1, W1, d.conv[1].kernel_h, d.conv[1].kernel_w);
         }
     }
     const bool in1_off = std::getenv("KWS_CNN_IN1") && std::atoi(std::getenv("KWS_CNN_IN1")) == 0;   // A/B and tests
@@ -708,6 +722,12 @@ size_t cnn_partial_bytes(const kws_handle* h, int cb) {
     return align256(mx);
 }
 
+size_t cnn_lin_elems(const kws_handle* h) {   // widest Linear output per clip
+    size_t mx = 1;
+    for (const auto& L : h->clin) mx = std::max(mx, (size_t)L.g.Cout * L.g.Ho * L.g.Wo);
+    return mx;
+}
+
 size_t act_bytes(const kws_handle* h, int B, int T) {
     if (h->plan == PLAN_RESNET) {
         if (use_fused(h, T)) return 0;   // (kws_forward's per-clip feature shifts live in a buffer of the handle: r8_shift)
@@ -724,7 +744,11 @@ size_t act_bytes(const kws_handle* h, int B, int T) {
     }
     if (h->plan == PLAN_CNN) {
         const int cb = cnn_chunk(h, B);
-        return 2 * align256(h->cnn_max_elems * cb * 4) + cnn_partial_bytes(h, cb) + align256((size_t)8 * h->d.time * h->d.freq * 4 + 4096);
+        // two flip buffers + split-K partials; with the side stream: a second buffer for what the Linears read, the gated pass's own flip pair, two small
+        // buffers between Linears
+        const size_t big = align256(h->cnn_max_elems * cb * 4);
+        return (h->side ? 5 : 2) * big + (h->side ? 2 * align256(cnn_lin_elems(h) * cb * 4) : 0) + cnn_partial_bytes(h, cb) +
+               align256((size_t)8 * h->d.time * h->d.freq * 4 + 4096);
     }
     return 0;
 }
@@ -1104,18 +1128,42 @@ bool cnn_in1_plan(const kws_handle* h, int mode) {
     return h->cnn_cl1 && f16 && h->clin0_cl.use_x && h->cconv[0].apk_in1[0].p != nullptr;
 }
 
-int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s) {
+int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws, hipStream_t s_main) {
     const kws_model_desc& d = h->d;
     if (T != d.time) return fail(KWS_EINVAL, "CNN was built for a different number of frames (config[\"time\"])");
     const int cb = cnn_chunk(h, B);
-    float* P = (float*)ws;
-    float* Q = (float*)(ws + align256(h->cnn_max_elems * cb * 4));
-    float* part = (float*)(ws + 2 * align256(h->cnn_max_elems * cb * 4));
-    const size_t part_bytes = cnn_partial_bytes(h, cb);
-    auto other = [&](const float* c) -> float* { return c == P ? Q : P; };
-    for (int b0 = 0; b0 < B; b0 += cb) {
+    const size_t big = align256(h->cnn_max_elems * cb * 4), part_bytes = cnn_partial_bytes(h, cb);
+    char* w = ws;
+    auto carve = [&](size_t n) { float* q = (float*)w; w += n; return q; };
+    float* P = carve(big);
+    float* Q = carve(big);
+    float* part = carve(part_bytes);
+    // (r5) two streams.  Per chunk the convolutions fill the chip (conv_in1 + conv_band: 185 of 234 us on cnn-trad-pool2 `fp16`) and the rest does not: a Linear of
+    // ~200 workgroups, its split-K reduce, the range guard's gated second pass (four launches that read a flag and return).  With more than one chunk in the
+    // call that tail runs on the handle's own stream while the caller's stream goes on with the next chunk's convolutions: fork after conv_1 (ev_fork), join
+    // two chunks later -- when the buffer the Linear reads and the chunk's flag word come round again (ev_join) -- and at the end of the call.  Same kernels on
+    // the same operands: the logits are bit-identical to the one-stream form (KWS_CNN_STREAMS=0; tested).  Under stream capture the side stream joins the
+    // capture at the first fork and has left it at the last join.
+    const int terms0 = dtype_terms(d.dtype);
+    const bool piped = h->side && B > cb && (cnn_band_plan(h, terms0) || cnn_in1_plan(h, terms0));
+    float *P1 = nullptr, *P2 = nullptr, *Q2 = nullptr, *T0 = nullptr, *T1 = nullptr;
+    if (h->side) {
+        P1 = carve(big); P2 = carve(big); Q2 = carve(big);
+        const size_t lin = align256(cnn_lin_elems(h) * cb * 4);
+        T0 = carve(lin); T1 = carve(lin);
+    }
+    const bool guarded = guarded_mode(h, terms0);
+    if (piped && guarded) HIP_TRY(hipMemsetAsync(h->range_flag.as<unsigned>(), 0, 2 * sizeof(unsigned), s_main));
+    int k = 0;
+    for (int b0 = 0; b0 < B; b0 += cb, ++k) {
         const int nb = std::min(cb, B - b0);
+        float* head_out = (k & 1) ? P1 : P;   // (two-stream form) what this chunk's first Linear reads
         auto pass = [&](int terms, RangeGate rg) -> int {
+            const bool on_side = piped && rg.gated;   // the gated pass of a two-stream chunk: the side stream, its own flip pair
+            hipStream_t s = on_side ? h->side : s_main, st = piped ? h->side : s_main;   // convolutions / Linears
+            float *FP = on_side ? P2 : P, *FQ = on_side ? Q2 : Q;
+            auto other = [&](const float* c) -> float* { return c == FP ? FQ : FP; };
+            auto lin_dst = [&](const float* c) -> float* { return piped && !rg.gated ? (c == T0 ? T1 : T0) : other(c); };
             const float* cur = feat + (size_t)b0 * d.time * d.freq;
             int m_f16, m_terms;
             decode_mode(terms, m_f16, m_terms);
@@ -1128,13 +1176,14 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             const bool cl1_f16 = cl1 && !band && m_f16 && m_terms == 1 && h->lin_in_f16 &&
                                  ((long long)(h->cconv[0].g.Ho / std::max(d.pool_kh[0], 1)) * (h->cconv[0].g.Wo / std::max(d.pool_kw[0], 1)) * h->cnn_cp[0]) % 8 == 0;
             if (band || cl1) {
+                float* c0_out = piped && !band ? head_out : Q;
                 // conv_0 (+ fused MaxPool) writes channels-last cells -- fp32, or fp16 with single-term products: from an LDS image
                 // of the clip (conv_in1.hip) where the layer fits it, else through the generic kernel's channels-last epilogue
                 int rcb;
                 if (h->cnn_in1) {
                     const ConvGeom& g0 = h->cconv[0].g;
                     In1ConvParams ip{};
-                    ip.feat = cur; ip.out = Q;
+                    ip.feat = cur; ip.out = c0_out;
                     ip.apk = h->cconv[0].apk_in1[m_terms == 1 ? 1 : 0].as<unsigned short>();
                     ip.bias = h->cconv[0].bias.as<float>();
                     ip.B = nb; ip.T = d.time; ip.F = d.freq; ip.Cout = g0.Cout; ip.Cp = h->cnn_cp[0]; ip.mtiles = g0.mtiles;
@@ -1151,15 +1200,15 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                     }
                     g0.out_cl = ((band && m_terms == 1) || cl1_f16) ? 2 : 1;   // fp16 cells for conv_band.hip, or for a Linear that would round them to fp16 anyway
                     g0.out_cp = h->cnn_cp[0];
-                    ConvArgs a0{cur, Q, h->cconv[0].apk.as<float>(), nullptr, h->cconv[0].bias.as<float>(), nullptr, nullptr, rg};
+                    ConvArgs a0{cur, c0_out, h->cconv[0].apk.as<float>(), nullptr, h->cconv[0].bias.as<float>(), nullptr, nullptr, rg};
                     if ((rcb = launch_layer(h->cconv[0], g0, a0, s, terms))) return rcb;
                 }
-                const float* lin_in = Q;
+                const float* lin_in = c0_out;
                 bool lin_f16 = cl1_f16;
                 if (band) {
                 const ConvGeom& g1 = h->cconv[1].g;
                 BandConvParams bp{};
-                bp.in = Q; bp.out = P;
+                bp.in = Q; bp.out = piped ? head_out : P;
                 bp.apk = h->cconv[1].apk_band.as<unsigned short>();
                 bp.bias = h->cconv[1].bias.as<float>();
                 bp.B = nb; bp.H = g1.H; bp.W = g1.W; bp.Cpi = h->cnn_cp[0];
@@ -1183,6 +1232,15 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                     if (rcz) return rcz;
                     bp.dbg_ts = band_buf.as<unsigned long long>();
                 }
+                if (h->cnn_cols && m_terms == 1 && h->cconv[1].apk_cols.p) {
+                    ColsConvParams cp{};
+                    cp.in = reinterpret_cast<const unsigned short*>(bp.in); cp.out = bp.out;
+                    cp.apk = h->cconv[1].apk_cols.as<unsigned short>(); cp.bias = bp.bias;
+                    cp.B = nb; cp.H = g1.H; cp.W = g1.W; cp.Cpi = bp.Cpi; cp.Ho = g1.Ho; cp.Wo = g1.Wo; cp.Cout = g1.Cout; cp.Cpo = bp.Cpo;
+                    cp.kh = g1.kh; cp.nbands = (g1.Ho + 15) / 16;
+                    cp.inv_scale = bp.inv_scale; cp.relu = 1; cp.out_f16 = bp.out_f16; cp.rg = rg; cp.dbg_ts = bp.dbg_ts;
+                    HIP_TRY(launch_conv_cols(cp, h->n_cu, s));
+                } else
                 HIP_TRY(launch_conv_band(bp, s));
                 if (band_this) {
                     std::vector<unsigned long long> z((size_t)8192 * 4 * 8);
@@ -1193,15 +1251,19 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                         std::fclose(f);
                     }
                 }
-                lin_in = P;
+                lin_in = bp.out;
+                }
+                if (piped) {
+                    HIP_TRY(hipEventRecord(h->ev_fork[k & 1], s));
+                    HIP_TRY(hipStreamWaitEvent(st, h->ev_fork[k & 1], 0));
                 }
                 ConvGeom gl = h->clin0_cl.g;
                 gl.B = nb;
                 gl.in_f16 = lin_f16 ? 1 : 0;
                 const bool last = h->clin.size() == 1;
-                float* dst = last ? logits + (size_t)b0 * d.n_labels : other(lin_in);
+                float* dst = last ? logits + (size_t)b0 * d.n_labels : lin_dst(lin_in);
                 ConvArgs al{lin_in, dst, h->clin0_cl.apk.as<float>(), nullptr, h->clin[0].bias.as<float>(), nullptr, nullptr, rg};
-                rcb = launch_conv_auto(h->clin0_cl, gl, al, nb, part, part_bytes, s, terms);
+                rcb = launch_conv_auto(h->clin0_cl, gl, al, nb, part, part_bytes, st, terms);
                 if (rcb) return rcb;
                 cur = dst;
                 first_lin = 1;
@@ -1232,19 +1294,32 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                 ConvGeom g = h->clin[i].g;
                 g.B = nb;
                 const bool last = i + 1 == h->clin.size();
-                float* dst = last ? logits + (size_t)b0 * d.n_labels : other(cur);
+                float* dst = last ? logits + (size_t)b0 * d.n_labels : lin_dst(cur);
                 ConvArgs a{cur, dst, h->clin[i].apk.as<float>(), nullptr, h->clin[i].bias.as<float>(), nullptr, nullptr, rg};
-                int rcl = launch_conv_auto(h->clin[i], g, a, nb, part, part_bytes, s, terms);
+                int rcl = launch_conv_auto(h->clin[i], g, a, nb, part, part_bytes, st, terms);
                 if (rcl) return rcl;
                 cur = dst;
             }
             return KWS_OK;
         };
-        int rc = run_guarded(h, dtype_terms(d.dtype), s, pass);
-        if (rc) return rc;
+        int rc;
+        if (!piped) {
+            if ((rc = run_guarded(h, terms0, s_main, pass))) return rc;
+            continue;
+        }
+        unsigned* flag = h->range_flag.as<unsigned>() + (k & 1);
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(s_main, h->ev_join[k & 1], 0));   // chunk k - 2 has let go of head_out and of the flag word
+        if ((rc = pass(terms0, RangeGate{guarded ? flag : nullptr, 0}))) return rc;
+        if (guarded) {
+            if ((rc = pass(RANGE_FREE_MODE, RangeGate{flag, 1}))) return rc;
+            HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), h->side));
+        }
+        HIP_TRY(hipEventRecord(h->ev_join[k & 1], h->side));
     }
+    if (piped) HIP_TRY(hipStreamWaitEvent(s_main, h->ev_join[(k - 1) & 1], 0));
     return KWS_OK;
 }
+
 
 // own_feat: the features come from this library's front end (log-mel values, far inside fp16's range)
 int run_model(kws_handle* h, const float* feat, int B, int T, float* logits, char* ws_act, hipStream_t s, bool own_feat) {
@@ -1396,6 +1471,21 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
         default: return fail(KWS_EINVAL, "unknown model family");
     }
     if (rc) return rc;
+    if (h->plan == PLAN_CNN) {
+        if (const char* tp = std::getenv("KWS_CNN_STREAMS")) h->cnn_streams = std::atoi(tp) != 0;   // A/B and tests: 0 = one stream
+        if (h->cnn_streams) {
+            // (the side stream's kernels are small and find the chip full of the next chunk's convolution workgroups: highest priority, so that they are
+            // dispatched as slots come free instead of behind the convolution's queue)
+            int prio_least = 0, prio_greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_greatest));
+            // the events order two streams of ONE device: no system-scope fence (an L2 write-back per record, ~8 us between conv_band and the next conv_in1)
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming | hipEventDisableSystemFence));
+                HIP_TRY(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming | hipEventDisableSystemFence));
+            }
+        }
+    }
     *out = h.release();
     return KWS_OK;
     });
@@ -1477,6 +1567,10 @@ int kws_load_weights(kws_handle* h, const char* name_in, const void* host_ptr, s
                     L.band_scale = weight_scale_pow2(src, (size_t)L.g.Cout * L.g.Cin * L.g.kh * L.g.kw);
                     pack_conv_band_weights(L.g.Cin, L.g.Cout, L.g.kh, L.g.kw, src, L.band_scale, pkb);
                     if ((rc = L.apk_band.upload(pkb.data(), pkb.size() * sizeof(unsigned short)))) return rc;
+                    if (h->cnn_cols) {
+                        pack_conv_cols_weights(L.g.Cin, L.g.Cout, L.g.kh, src, L.band_scale, pkb);
+                        if ((rc = L.apk_cols.upload(pkb.data(), pkb.size() * sizeof(unsigned short)))) return rc;
+                    }
                 }
             } else {
                 if ((rc = need(L.g.Cout))) return rc;

@@ -514,6 +514,23 @@ bool conv_band_plan(int Cin, int Cout, int H, int W, int kh, int kw, int parts, 
 size_t conv_band_lds_bytes(int Cpi, int kh, int kw, int PS, int parts);
 void pack_conv_band_weights(int Cin, int Cout, int kh, int kw, const float* w, float scale, std::vector<unsigned short>& dst);
 hipError_t launch_conv_band(const BandConvParams& p, hipStream_t s);
+// conv_cols.hip: the same layer on fp16 tensors with column tiles, persistent and double-buffered (one workgroup per CU)
+struct ColsConvParams {
+    const unsigned short* in;    // channels-last fp16 cells (B, H, W, Cpi)
+    void* out;                   // channels-last (B, Ho, Wo, Cpo): fp16 cells (out_f16) or fp32, zeros in the padding
+    const unsigned short* apk;   // pack_conv_cols_weights
+    const float* bias;           // (Cout)
+    int B, H, W, Cpi, Ho, Wo, Cout, Cpo;
+    int kh;                      // kernel rows (four kernel columns)
+    int nbands;                  // ceil(Ho / 16): bands of 16 output rows, the last one moved up to end on row Ho - 1
+    float inv_scale;             // 2^-S of the weights
+    int relu, out_f16;
+    RangeGate rg;
+    unsigned long long* dbg_ts;  // KWS_BAND_TIMING (with a -DCOLS_TIMING build): phase stamps of the first 512 workgroups' units, or nullptr
+};
+bool conv_cols_supported(int Cin, int Cout, int H, int W, int kh, int kw);
+void pack_conv_cols_weights(int Cin, int Cout, int kh, const float* w, float scale, std::vector<unsigned short>& dst);
+hipError_t launch_conv_cols(const ColsConvParams& p, int n_cu, hipStream_t s);
 // fp32 (B, C, H, W) -> pooled (stride = window, floor; 1 x 1 = transpose only) channels-last (B, H/kh, W/kw, cp) fp32
 hipError_t launch_nchw_to_cl(const float* in, float* out, int B, int C, int H, int W, int kh, int kw, int is_max, int cp,
                              hipStream_t s, RangeGate rg = RangeGate{nullptr, 0});

@@ -1543,3 +1543,56 @@ def test_fp16_cells_between_conv_1_and_the_linear_change_no_bit(torch_cuda, monk
             outs[knob] = m(x)
             assert m.plan_name() == plan, (fname, m.plan_name())
         assert torch.isfinite(outs["1"]).all() and torch.equal(outs["1"], outs["0"]), (fname, float((outs["1"] - outs["0"]).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname,dtype", [("model_cnn__cnn-trad-pool2.npz", "fp16"), ("model_cnn__cnn-trad-pool2.npz", "f32"),
+                                         ("model_cnn__cnn-one-fstride4.npz", "fp16"), ("model_cnn__cnn-tstride8.npz", "f32")])
+def test_cnn_two_stream_chunks_change_no_bit(torch_cuda, monkeypatch, fname, dtype):
+    """cnn plans, calls of more than one chunk (reference model/cnn.py:79-107 over a batch): a chunk's Linears, split-K reduces and the range guard's gated
+    second pass run on a stream of the handle while the caller's stream computes the next chunk's convolutions (run_cnn, two buffers for what the Linear
+    reads, two flag words).  Same kernels on the same operands, so 3 300 clips -- four chunks, the last ragged, the SECOND one driven out of fp16's range so
+    that its recomputation overlaps the third chunk's first pass -- must give the one-stream form's logits bit for bit, eagerly, from a stream that is not
+    the default one, and replayed from a captured graph."""
+    torch = torch_cuda
+    from oracle import weights
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    n = 3300
+    f = weights.make_features(n, seed=41)
+    f[1024:2048] *= 40000.0
+    x = torch.from_numpy(f).cuda()
+    monkeypatch.setenv("KWS_CNN_STREAMS", "0")
+    one = _build(torch, name, dict(cfg, dtype=dtype), sd)
+    want = one(x).clone()
+    monkeypatch.delenv("KWS_CNN_STREAMS")
+    two = _build(torch, name, dict(cfg, dtype=dtype), sd)
+    for _ in range(3):
+        got = two(x)
+        assert torch.isfinite(got).all() and torch.equal(got, want), float((got - want).abs().max())
+    assert two.plan_name() == one.plan_name()
+    big = float(want[1024:2048].abs().max())
+    assert big > 3e3                                               # the driven chunk really was recomputed
+    if dtype == "f32":                                             # ... to fp32 accuracy (the gated pass walks its positions with 512 workgroups)
+        from oracle import models
+        ref = models.forward_torch(name, cfg, sd, f[1024:2048]).numpy()
+        assert np.abs(want[1024:2048].cpu().numpy() - ref).max() < 3e-6 * big
+    static_in = x.clone()
+    out = torch.empty((n, cfg["n_labels"]), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        two(static_in, out=out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+        with torch.cuda.graph(graph, stream=side):
+            two(static_in, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    x2 = torch.from_numpy(weights.make_features(n, seed=42)).cuda()
+    want2 = one(x2).clone()
+    for src, w in ((x2, want2), (x, want), (x2, want2)):
+        static_in.copy_(src)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, w), float((out - w).abs().max())

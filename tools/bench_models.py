@@ -44,6 +44,8 @@ def main():
         model = model.to(dev).eval()
         batch = int(os.environ.get("KWS_BENCH_BATCH", "0")) or (8192 if MFLOP[tag] < 400 else 2048)
         x = torch.randn(batch, 101, 40, device=dev) * 2.5 + 0.65
+        if os.environ.get("KWS_BENCH_ZERO") == "1":       # all-zero features: the same instruction stream with (almost) no switching activity in the matrix pipe
+            x.zero_()
         model(x[:64])
         model(x)                       # full-batch warm-up: the workspace grows to its final size here, not in the timed calls
         torch.cuda.synchronize()
@@ -55,15 +57,36 @@ def main():
             model(x)
         torch.cuda.synchronize()
         reps = max(3, min(200, int(0.25 / one)))
+        power = None
+        if os.environ.get("KWS_BENCH_POWER") == "1":      # ~3 s of calls with rocm-smi sampled beside them: package power and shader clock under this model
+            import re, subprocess, threading
+            samples, stop = [], [False]
+
+            def sample():
+                while not stop[0]:
+                    try:
+                        samples.append(subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout[:600])
+                    except Exception as e:
+                        samples.append(repr(e))
+                    time.sleep(0.25)
+            th = threading.Thread(target=sample)
+            th.start()
+            reps = max(reps, int(3.0 / one))
         t0 = time.perf_counter()
         for _ in range(reps):
             model(x)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
+        if os.environ.get("KWS_BENCH_POWER") == "1":
+            stop[0] = True
+            th.join()
+            pw = [float(m.group(1)) for smp in samples[2:] for m in [re.search(r'Package Power \(W\)": "([0-9.]+)"', smp)] if m]
+            ck = [float(m.group(1)) for smp in samples[2:] for m in [re.search(r'sclk clock speed:": "\(([0-9.]+)Mhz', smp)] if m]
+            power = {"W": round(sum(pw) / max(len(pw), 1)), "sclk_MHz": round(sum(ck) / max(len(ck), 1)), "samples": len(pw)}
         cps = batch / dt
         print(json.dumps({"model": tag, "plan": model.plan_name(), "dtype": dtype, "batch": batch, "ms": round(dt * 1e3, 2),
                           "clips_per_s": round(cps), "TFLOPs_alg": round(cps * MFLOP[tag] * 1e6 / 1e12, 2),
-                          "frac_of_roof": round(cps * MFLOP[tag] * 1e6 / 1e12 / peak, 3), "roof_TFLOPs": round(peak, 1)}), flush=True)
+                          "frac_of_roof": round(cps * MFLOP[tag] * 1e6 / 1e12 / peak, 3), "roof_TFLOPs": round(peak, 1), **({"power": power} if power else {})}), flush=True)
         del model
         torch.cuda.empty_cache()
 
