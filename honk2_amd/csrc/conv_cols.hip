@@ -1,5 +1,5 @@
 // Second convolution of the two-conv cnn-* models on fp16 tensors (`fp16` dtype; reference model/cnn.py:46-62: Conv2d(C0, C1, (kh, 4), stride 1, no
-// padding) + bias -> ReLU, pool_1 the identity): a persistent, double-buffered form of conv_band.hip's idea with COLUMN tiles.
+// padding) + bias -> ReLU, pool_1 the identity): a persistent form of conv_band.hip's idea with COLUMN tiles.
 //
 // conv_band_kernel (one workgroup per band, position tiles by residue class) is bound by two things (tools/band_phases.py): its k-loop
 // reads one 1 KB B fragment from LDS per two MFMAs -- 96 of the CU's 128 B/clk at 76 % of the matrix rate -- and the two workgroups of a CU stage, compute
@@ -9,13 +9,14 @@
 //     the 16 cells (row + dy, x + dx) -- a function of the input column c = x + dx alone: one fragment F(c) per (dy, cq) sweep serves kw = 4 taps of up to
 //     four tiles.  A wave owns MH channel tiles x NX <= 7 columns: per sweep NX + 3 LDS reads and 4 MH weight fragments feed 4 MH NX MFMAs (56 for
 //     cnn-trad-pool2: 5.6 MFMAs per LDS read instead of 2; every one of the 32 x 13 outputs sits in a tile: 1 120 MFMAs per wave and band instead of 1 280);
-//   * workgroups of four waves (wave = channel half x column half), TWO per CU, each persistent over a contiguous run of (clip, band) units with ONE LDS
-//     image: the next unit's 25 input rows are requested with global_load_lds_dwordx4 (memory -> LDS, no registers) once every wave has left the k-loop and
-//     land while the epilogue runs -- and while the CU's other workgroup computes: a lone wave per SIMD issues an MFMA every ~27 cycles however its operands
-//     arrive (measured: the first version, one double-buffered workgroup per CU, ran its 1 120 MFMAs per unit in 30 k cycles with every load ablated), two reach
-//     the pipe's rate, and two persistent workgroups drift out of phase by themselves.  The image is a flat copy with one spare 16-byte slot per row, so that
-//     the 16 rows of a fragment fall on 16 different bank groups (row stride = an odd number of 16-byte slots);
-//   * one set of fragment registers, refilled in place a sweep ahead; two sets of weight fragments (cols_kloop).
+//   * workgroups of four waves (wave = channel half x column half), TWO per CU, each persistent over (clip, band) units drawn from a device-wide counter,
+//     with ONE LDS image: the next unit's 25 input rows are requested with global_load_lds_dwordx4 (memory -> LDS, no registers) once every wave has left the
+//     k-loop and land while the epilogue runs -- and while the CU's other workgroup computes.  (The first version, one double-buffered workgroup per CU, ran
+//     its 1 120 MFMAs per unit in 30 k cycles with every load ablated: a lone wave per SIMD does not reach the pipe's rate.)  The image is four planes, one per
+//     lane group, rows an odd number of 16-byte slots apart: fragment reads without bank conflicts (cols_image_bytes); the DMA fills it in any order it likes,
+//     since every lane names its own 16 source bytes;
+//   * one set of fragment registers, refilled in place a sweep ahead; two sets of weight fragments, all of the next sweep's requested in front of this
+//     sweep's first tile; a tile's four taps as one chain on its accumulator (cols_kloop).
 //
 // in: channels-last fp16 cells (B, H, W, Cpi = 64); out: channels-last (B, Ho, Wo, Cpo) fp16 or fp32 cells, exact zeros in the channel padding; weights
 // x 2^S as fp16 fragments in sweep order (pack_conv_cols_weights).  Same products in a different summation order than conv_band_kernel (K runs (dy, cq, dx)
@@ -40,13 +41,14 @@ constexpr int COLS_KW = 4;
 constexpr int COLS_ROWS = 16;      // output rows per band = lanes of a position tile
 
 // The k-loop of a wave that owns NXW output columns (x0 .. x0 + NXW - 1) and MH channel tiles; CB = bytes per cell, NQ = channel quads per cell.
-// Sweep t = dy * NQ + cq; fragment c of sweep t is read at fbase + dy * rsb + cq * 64 + c * CB.  ONE set of NC fragment registers: column c's register is
+// Sweep t = dy * NQ + cq; fragment c of sweep t is read at fbase + dy * rsb + cq * 16 + c * NQ * 16 (plane g of the image, cols_image_bytes).  ONE set of NC fragment registers: column c's register is
 // refilled with the next sweep's column c as soon as this sweep's MFMAs on it are issued (a sweep -- ~900 cycles -- ahead of its use); the weight fragments
 // have two sets (a fragment's last use in a sweep is only ~4 columns before its first use in the next: less than an L2 round trip).
 template <int MH, int NXW, int CB, int NQ>
 __device__ __forceinline__ void cols_kloop(const __amdgpu_buffer_rsrc_t ars, const int avoff, const int fbase, const int rsb, const int kh,
                                            f32x4 (&acc)[MH][7], u32x4 (&a0)[COLS_KW][MH]) {
     constexpr int NC = NXW + COLS_KW - 1;
+    constexpr int FS = NQ * 16;                           // bytes between the fragments of neighbouring columns in an LDS plane
     constexpr int ASWEEP_B = COLS_KW * 2 * MH * 1024;     // bytes of weight fragments per sweep: [dx][2 MH channel tiles][64 lanes] x 16 B
     const int nsweep = kh * NQ;
     u32x4 a1[COLS_KW][MH], f[NC];
@@ -57,18 +59,21 @@ __device__ __forceinline__ void cols_kloop(const __amdgpu_buffer_rsrc_t ars, con
     };
     auto faddr = [&](int t) {
         const int dy = t / NQ, cq = t - dy * NQ;
-        return fbase + __builtin_amdgcn_readfirstlane(dy * rsb + cq * 64);
+        return fbase + __builtin_amdgcn_readfirstlane(dy * rsb + cq * 16);
     };
     {
         const int ad = faddr(0);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) f[c] = cols_lds_read16(ad + c * CB);
+        for (int c = 0; c < NC; ++c) f[c] = cols_lds_read16(ad + c * FS);
     }
     // one sweep: the MFMAs of (ac, f) tile by tile -- a tile's four taps as ONE chain on its accumulator (at the power cap a dependent MFMA is cheaper than an
     // independent one: it takes C from the MFMA in front of it) -- with the next sweep's weights into an and its fragments into f between them
     auto sweep = [&](const u32x4 (&ac)[COLS_KW][MH], u32x4 (&an)[COLS_KW][MH], int tn, int adn) {
         const int so = __builtin_amdgcn_readfirstlane(tn * ASWEEP_B);
-        constexpr int APS = (COLS_KW * MH + NXW - 1) / NXW;      // weight fragments requested per tile
+#ifndef COLS_APS
+#define COLS_APS (COLS_KW * MH)     // weight fragments requested per tile: all of them in front of the first one -- every tile needs all four taps' fragments, so the last one requested is needed as early as the first
+#endif
+        constexpr int APS = COLS_APS;
 #pragma unroll
         for (int x = 0; x < NXW; ++x) {
             if (!(COLS_ABLATE & 1)) {
@@ -88,11 +93,11 @@ __device__ __forceinline__ void cols_kloop(const __amdgpu_buffer_rsrc_t ars, con
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!(COLS_ABLATE & 2)) f[x] = cols_lds_read16(adn + x * CB);      // (column x is done with: tiles x - 3 .. x were its users)
+            if (!(COLS_ABLATE & 2)) f[x] = cols_lds_read16(adn + x * FS);      // (column x is done with: tiles x - 3 .. x were its users)
         }
         if (!(COLS_ABLATE & 2)) {
 #pragma unroll
-            for (int c = NXW; c < NC; ++c) f[c] = cols_lds_read16(adn + c * CB);
+            for (int c = NXW; c < NC; ++c) f[c] = cols_lds_read16(adn + c * FS);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -112,11 +117,14 @@ __device__ __forceinline__ void cols_kloop(const __amdgpu_buffer_rsrc_t ars, con
 }
 }  // namespace
 
-// LDS bytes of the image: rows_in rows of (W * Cpi * 2 + 16) bytes, in whole 1 KB DMA pieces
-__host__ __device__ inline int cols_image_bytes(int W, int Cpi, int kh) {
-    const int rsb = W * Cpi * 2 + 16, rows_in = COLS_ROWS + kh - 1;
-    return (rows_in * rsb + 1023) / 1024 * 1024;
-}
+// LDS image: four PLANES, one per lane group g (a ds_read_b128 is conflict-free iff the 16 rows of a fragment differ mod 16 slots AND the lane groups' slots
+// coincide: blocks of one cell 16 bytes apart cost every second LDS cycle, measured); plane g holds, per input row, slot col * NQ + cq = channel block 4 cq + g
+// of cell (row, col), rows one spare slot apart (an odd number of slots), planes a multiple of 16 slots apart.
+__host__ __device__ inline int cols_row_slots(int W, int Cpi) { return W * ((Cpi + 31) / 32) + 1; }
+__host__ __device__ inline int cols_plane_slots(int W, int Cpi, int kh) { return ((COLS_ROWS + kh - 1) * cols_row_slots(W, Cpi) + 15) / 16 * 16; }
+__host__ __device__ inline int cols_image_bytes(int W, int Cpi, int kh) { return (4 * cols_plane_slots(W, Cpi, kh) * 16 + 1023) / 1024 * 1024; }
+// + one word per 16-byte slot (where the slot's bytes sit in memory relative to the band's first input row) + the next unit's number
+static size_t cols_lds_bytes(int W, int Cpi, int kh) { return (size_t)cols_image_bytes(W, Cpi, kh) * 5 / 4 + 16; }
 
 template <int MH, int CPI16>
 __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
@@ -131,16 +139,17 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
     const int wm = w & 1, wn = w >> 1;
     const int g = lane >> 4, pcol = lane & 15;
     const int rb = p.W * CB;                   // bytes per input row in memory
-    const int rsb = rb + 16;                   // ... in LDS
-    const int rbc = rb / 16;                   // 16-byte slots per row in memory
+    const int slr = cols_row_slots(p.W, CPI16 * 16), rsb = slr * 16;      // slots / bytes per row of an LDS plane
+    const int ps = cols_plane_slots(p.W, CPI16 * 16, p.kh);
     const int rows_in = COLS_ROWS + p.kh - 1;
     const int npiece = cols_image_bytes(p.W, CPI16 * 16, p.kh) / 1024;
 
-    // contiguous run of (clip, band) units of this workgroup
+    // (clip, band) units: the first one by workgroup index, the rest drawn from a device-wide counter -- the two workgroups of a CU do not progress at the
+    // same rate (arbitration favours the older waves: with four units each the favoured one was done after 70 us and the other ran its last two alone)
     const int nunit = p.B * p.nbands;
-    const int per = (nunit + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int u_begin = (int)blockIdx.x * per, u_end = min(nunit, u_begin + per);
-    if (u_begin >= u_end) return;
+    if ((int)blockIdx.x >= nunit) return;      // (the launcher keeps the grid within the units)
+    int* const next_slot = reinterpret_cast<int*>(lds + npiece * 1024 * 5 / 4);
+    const int u_begin = (int)blockIdx.x;
 
     auto unit_rows = [&](int u, int& b, int& r0, int& row_lo) {
         b = u / p.nbands;
@@ -148,20 +157,25 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
         r0 = min(band * COLS_ROWS, p.Ho - COLS_ROWS);    // the last band is moved up to end on the last row; rows the band before it owns are not stored again
         row_lo = band * COLS_ROWS - r0;
     };
-    // the image of unit u: this wave's 1 KB pieces w, w + 4, ...  LDS slot s = 64 piece + lane holds slot s % (rbc + 1) of row s / (rbc + 1); the spare slot of
-    // a row and the slots past the image repeat a neighbour's bytes (finite values that nothing reads, or that meet zero weights)
+    // the image of unit u: this wave's 1 KB pieces w, w + 4, ...; LDS slot s = 64 piece + lane is slot s % ps of plane s / ps.  Where each slot's 16 bytes sit
+    // relative to the band's first input row does not depend on the unit: computed once, kept in LDS behind the image (one word per lane and piece, written
+    // and read by the same lane: 13 - 20 registers otherwise).  The spare slot of a row and the slots past a plane repeat a neighbour's bytes: finite values
+    // that nothing reads.
+    int* const dtab = reinterpret_cast<int*>(lds + npiece * 1024);
+    for (int pc = w; pc < npiece; pc += 4) {
+        const int sl = pc * 64 + lane;
+        const int gq = min(sl / ps, 3), sp = sl - (sl / ps) * ps;
+        const int rw = min(sp / slr, rows_in - 1), j = min(sp - (sp / slr) * slr, slr - 2);
+        const int col = j / NQ, cq = j - col * NQ;
+        dtab[pc * 64 + lane] = rw * rb + col * CB + (cq * 4 + gq) * 16;
+    }
     auto dma_unit = [&](int u) {
-        if (COLS_ABLATE & 8) {
-            if (u != u_begin) return;
-        }
+        if ((COLS_ABLATE & 8) && u != u_begin) return;
         int b, r0, lo;
         unit_rows(u, b, r0, lo);
         const char* src = reinterpret_cast<const char*>(p.in) + ((size_t)b * p.H + r0) * rb;
         for (int pc = w; pc < npiece; pc += 4) {
-            const int s = pc * 64 + lane;
-            const int rw = s / (rbc + 1);
-            const int off = min(rw, rows_in - 1) * rb + min(s - rw * (rbc + 1), rbc - 1) * 16;
-            const __attribute__((address_space(1))) void* gsrc = (const __attribute__((address_space(1))) void*)(src + off);
+            const __attribute__((address_space(1))) void* gsrc = (const __attribute__((address_space(1))) void*)(src + dtab[pc * 64 + lane]);
             __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)(lds + pc * 1024), 16, 0, 0);
         }
     };
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
     const int x0 = wn ? nx0 : 0, nxw = wn ? p.Wo - nx0 : nx0;
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk), 0, p.kh * NQ * (COLS_KW * 2 * MH * 1024), 0x00020000);
     const int avoff = lane * 16 + (wm * MH) * 1024;
-    const int fbase = pcol * rsb + g * 16 + x0 * CB;
+    const int fbase = g * ps * 16 + pcol * rsb + x0 * (NQ * 16);
     float amax = 0.f;
     f32x4 bias_v[MH];      // (loaded here, not in the epilogue: a load there waits for the image pieces requested just before it -- vmcnt counts in order)
 #pragma unroll
@@ -191,12 +205,14 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
 
 #ifdef COLS_TIMING   // 100 MHz wall-clock stamps of this workgroup's phases, per unit (tools/cols_phases.py)
     unsigned long long cts[5];
+    int nts = 0;
 #define COLS_TS(i) cts[i] = __builtin_amdgcn_s_memrealtime();
 #else
 #define COLS_TS(i)
 #endif
-    for (int u = u_begin; u < u_end; ++u) {
+    for (int u = u_begin, nu = 0; u < nunit; u = nu) {
         COLS_TS(0)
+        if (tid == 0) *next_slot = (int)(gridDim.x + atomicAdd(p.queue, 1u));      // the unit after this one: known to everyone behind the k-loop's barrier
         f32x4 acc[MH][7];
 #pragma unroll
         for (int m = 0; m < MH; ++m)
@@ -211,12 +227,13 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
         COLS_TS(1)
         __syncthreads();      // every wave has issued its last MFMA on this image (the re-reads still in flight are never used)
         COLS_TS(2)
-        if (u + 1 < u_end) dma_unit(u + 1);      // ... so the next one may land while the epilogue runs (and the CU's other workgroup computes)
+        nu = __builtin_amdgcn_readfirstlane(*next_slot);
+        if (nu < nunit) dma_unit(nu);      // ... so the next one may land while the epilogue runs (and the CU's other workgroup computes)
 
         // ---------------------------------------------------------------- epilogue: bias, ReLU, channels-last cells
         int b, r0, row_lo;
         unit_rows(u, b, r0, row_lo);
-        const bool row_ok = pcol >= row_lo && !((COLS_ABLATE & 4) && u > u_begin);
+        const bool row_ok = pcol >= row_lo && !((COLS_ABLATE & 4) && u != u_begin);
         const size_t obase = ((size_t)b * p.Ho + r0 + pcol) * p.Wo + x0;
 #pragma unroll
         for (int m = 0; m < MH; ++m) {
@@ -250,13 +267,14 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
         __syncthreads();      // everyone's pieces of the next image have landed
 #ifdef COLS_TIMING
         COLS_TS(4)
-        if (p.dbg_ts && lane == 0 && blockIdx.x < 512 && u - u_begin < 8) {
-            unsigned long long* o = p.dbg_ts + (((size_t)blockIdx.x * 4 + w) * 8 + (u - u_begin)) * 8;
+        if (p.dbg_ts && lane == 0 && blockIdx.x < 512 && nts < 8) {
+            unsigned long long* o = p.dbg_ts + (((size_t)blockIdx.x * 4 + w) * 8 + nts++) * 8;
             for (int i = 0; i < 5; ++i) o[i] = cts[i];
             o[5] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
         }
 #endif
     }
+    if (tid == 0) queue_retire(p.queue);
     range_note(p.rg, amax);
 }
 
@@ -264,8 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
 bool conv_cols_supported(int Cin, int Cout, int H, int W, int kh, int kw) {
     const int Cpi = (Cin + 15) / 16 * 16, Ho = H - kh + 1, Wo = W - kw + 1, mh = conv_band_mh(Cout);
     if (kw != COLS_KW || Cpi != 64 || mh != 2 || Wo < 2 || Wo > 14 || Ho < COLS_ROWS) return false;
-    const int img = cols_image_bytes(W, Cpi, kh);
-    if (img > 80 * 1024 - 256) return false;      // two workgroups per CU
+    if (cols_lds_bytes(W, Cpi, kh) > 80 * 1024 - 256) return false;      // two workgroups per CU
     // rows computed / rows needed (the last band overlaps the one before it): not below 0.85
     const int nb = (Ho + COLS_ROWS - 1) / COLS_ROWS;
     return (double)Ho / (nb * COLS_ROWS) >= 0.85;
@@ -299,7 +316,7 @@ static hipError_t launch_cols_mh(const ColsConvParams& p, int n_cu, hipStream_t 
         if (e != hipSuccess) return e;
     }
     const int nunit = p.B * p.nbands;
-    const size_t lds = (size_t)cols_image_bytes(p.W, p.Cpi, p.kh);
+    const size_t lds = cols_lds_bytes(p.W, p.Cpi, p.kh);
     hipLaunchKernelGGL(k, dim3((unsigned)std::min(nunit, 2 * std::max(n_cu, 1))), dim3(256), lds, s, p);
     return hipGetLastError();
 }
@@ -307,8 +324,8 @@ static hipError_t launch_cols_mh(const ColsConvParams& p, int n_cu, hipStream_t 
 hipError_t launch_conv_cols(const ColsConvParams& p, int n_cu, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     const int mh = conv_band_mh(p.Cout);
-    if (p.Cpi != 64 || mh != 2 || p.Cpo % 16 || p.Cpo < p.Cout || p.Cpo > 32 * mh || p.Ho != p.H - p.kh + 1 || p.Wo != p.W - COLS_KW + 1 || p.Wo > 14 || p.Ho < COLS_ROWS ||
-        p.nbands != (p.Ho + COLS_ROWS - 1) / COLS_ROWS || cols_image_bytes(p.W, p.Cpi, p.kh) > 80 * 1024 - 256)
+    if (!p.queue || p.Cpi != 64 || mh != 2 || p.Cpo % 16 || p.Cpo < p.Cout || p.Cpo > 32 * mh || p.Ho != p.H - p.kh + 1 || p.Wo != p.W - COLS_KW + 1 || p.Wo > 14 || p.Ho < COLS_ROWS ||
+        p.nbands != (p.Ho + COLS_ROWS - 1) / COLS_ROWS || cols_lds_bytes(p.W, p.Cpi, p.kh) > 80 * 1024 - 256)
         return hipErrorInvalidValue;
     return launch_cols_mh<2>(p, n_cu, s);
 }

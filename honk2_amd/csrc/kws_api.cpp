@@ -178,12 +178,13 @@ struct kws_handle {
     int t3_stream = 1;                     // tiled plan, 16-bit tensors, 41-48 channels: runs of three layers and odd single layers as persistent weight-stationary streams (conv3x3_stream.hip; launches of >= 7 680 cells per CU; KWS_T3_STREAM=0: the tile kernels only; 2: launches of any size; 3: odd-first runs only)
     DevMem r8_shift;                       // fused res8, kws_forward: per-clip power-of-two shifts of caller-provided features (feat_shift_kernel)
     std::vector<void*> parked;             // outgrown r8_shift blocks: a captured graph may still name them, so they live as long as the handle
-    DevMem range_flag;                     // device words: [0] (and [1]: odd chunks of the two-stream cnn plan) fp16 range guard of the layer-wise plans
+    DevMem range_flag;                     // device words: [0] (and [1], [2]: the other chunks in flight on the two-stream cnn plan) fp16 range guard of the layer-wise plans
                                            // (kws_internal.h), [16] / [32] clip / unit counters of the fused res8 and front-end kernels
     // cnn plans, calls of more than one chunk: a chunk's Linears, split-K reduces and gated second pass run on a stream of the handle while the caller's
     // stream goes on with the next chunk's convolutions (run_cnn; KWS_CNN_STREAMS=0: everything on the caller's stream)
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+    static constexpr int CNN_RING = 3;     // chunks in flight between the two streams: buffers for what the Linear reads, flag words, events
+    hipEvent_t ev_fork[CNN_RING] = {}, ev_join[CNN_RING] = {};
     bool cnn_streams = true;
 
     // profiling
@@ -198,7 +199,7 @@ struct kws_handle {
     ~kws_handle() {
         for (auto e : ev_pool) (void)hipEventDestroy(e);
         for (void* q : parked) (void)hipFree(q);
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CNN_RING; ++i) {
             if (ev_fork[i]) (void)hipEventDestroy(ev_fork[i]);
             if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
         }
@@ -747,7 +748,7 @@ size_t act_bytes(const kws_handle* h, int B, int T) {
         // two flip buffers + split-K partials; with the side stream: a second buffer for what the Linears read, the gated pass's own flip pair, two small
         // buffers between Linears
         const size_t big = align256(h->cnn_max_elems * cb * 4);
-        return (h->side ? 5 : 2) * big + (h->side ? 2 * align256(cnn_lin_elems(h) * cb * 4) : 0) + cnn_partial_bytes(h, cb) +
+        return (h->side ? 6 : 2) * big + (h->side ? 2 * align256(cnn_lin_elems(h) * cb * 4) : 0) + cnn_partial_bytes(h, cb) +
                align256((size_t)8 * h->d.time * h->d.freq * 4 + 4096);
     }
     return 0;
@@ -1141,23 +1142,26 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
     // (r5) two streams.  Per chunk the convolutions fill the chip (conv_in1 + conv_band: 185 of 234 us on cnn-trad-pool2 `fp16`) and the rest does not: a Linear of
     // ~200 workgroups, its split-K reduce, the range guard's gated second pass (four launches that read a flag and return).  With more than one chunk in the
     // call that tail runs on the handle's own stream while the caller's stream goes on with the next chunk's convolutions: fork after conv_1 (ev_fork), join
-    // two chunks later -- when the buffer the Linear reads and the chunk's flag word come round again (ev_join) -- and at the end of the call.  Same kernels on
+    // three chunks later -- when the buffer the Linear reads and the chunk's flag word come round again (ev_join; with a ring of two the side stream, whose
+    // gated launches find no free wave slot beside the persistent conv_cols_kernel and finish right behind it, held the caller's stream up by ~10 us per
+    // chunk) -- and at the end of the call.  Same kernels on
     // the same operands: the logits are bit-identical to the one-stream form (KWS_CNN_STREAMS=0; tested).  Under stream capture the side stream joins the
     // capture at the first fork and has left it at the last join.
     const int terms0 = dtype_terms(d.dtype);
     const bool piped = h->side && B > cb && (cnn_band_plan(h, terms0) || cnn_in1_plan(h, terms0));
-    float *P1 = nullptr, *P2 = nullptr, *Q2 = nullptr, *T0 = nullptr, *T1 = nullptr;
+    constexpr int RING = kws_handle::CNN_RING;
+    float *P1 = nullptr, *P3 = nullptr, *P2 = nullptr, *Q2 = nullptr, *T0 = nullptr, *T1 = nullptr;
     if (h->side) {
-        P1 = carve(big); P2 = carve(big); Q2 = carve(big);
+        P1 = carve(big); P3 = carve(big); P2 = carve(big); Q2 = carve(big);
         const size_t lin = align256(cnn_lin_elems(h) * cb * 4);
         T0 = carve(lin); T1 = carve(lin);
     }
     const bool guarded = guarded_mode(h, terms0);
-    if (piped && guarded) HIP_TRY(hipMemsetAsync(h->range_flag.as<unsigned>(), 0, 2 * sizeof(unsigned), s_main));
+    if (piped && guarded) HIP_TRY(hipMemsetAsync(h->range_flag.as<unsigned>(), 0, RING * sizeof(unsigned), s_main));
     int k = 0;
     for (int b0 = 0; b0 < B; b0 += cb, ++k) {
         const int nb = std::min(cb, B - b0);
-        float* head_out = (k & 1) ? P1 : P;   // (two-stream form) what this chunk's first Linear reads
+        float* head_out = k % RING == 0 ? P : k % RING == 1 ? P1 : P3;   // (two-stream form) what this chunk's first Linear reads
         auto pass = [&](int terms, RangeGate rg) -> int {
             const bool on_side = piped && rg.gated;   // the gated pass of a two-stream chunk: the side stream, its own flip pair
             hipStream_t s = on_side ? h->side : s_main, st = piped ? h->side : s_main;   // convolutions / Linears
@@ -1239,6 +1243,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                     cp.B = nb; cp.H = g1.H; cp.W = g1.W; cp.Cpi = bp.Cpi; cp.Ho = g1.Ho; cp.Wo = g1.Wo; cp.Cout = g1.Cout; cp.Cpo = bp.Cpo;
                     cp.kh = g1.kh; cp.nbands = (g1.Ho + 15) / 16;
                     cp.inv_scale = bp.inv_scale; cp.relu = 1; cp.out_f16 = bp.out_f16; cp.rg = rg; cp.dbg_ts = bp.dbg_ts;
+                    cp.queue = h->range_flag.as<unsigned>() + 16;   // (the fused res8 kernel's words: no cnn handle runs that kernel)
                     HIP_TRY(launch_conv_cols(cp, h->n_cu, s));
                 } else
                 HIP_TRY(launch_conv_band(bp, s));
@@ -1254,8 +1259,8 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                 lin_in = bp.out;
                 }
                 if (piped) {
-                    HIP_TRY(hipEventRecord(h->ev_fork[k & 1], s));
-                    HIP_TRY(hipStreamWaitEvent(st, h->ev_fork[k & 1], 0));
+                    HIP_TRY(hipEventRecord(h->ev_fork[k % RING], s));
+                    HIP_TRY(hipStreamWaitEvent(st, h->ev_fork[k % RING], 0));
                 }
                 ConvGeom gl = h->clin0_cl.g;
                 gl.B = nb;
@@ -1307,16 +1312,16 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
             if ((rc = run_guarded(h, terms0, s_main, pass))) return rc;
             continue;
         }
-        unsigned* flag = h->range_flag.as<unsigned>() + (k & 1);
-        if (k >= 2) HIP_TRY(hipStreamWaitEvent(s_main, h->ev_join[k & 1], 0));   // chunk k - 2 has let go of head_out and of the flag word
+        unsigned* flag = h->range_flag.as<unsigned>() + k % RING;
+        if (k >= RING) HIP_TRY(hipStreamWaitEvent(s_main, h->ev_join[k % RING], 0));   // chunk k - RING has let go of head_out and of the flag word
         if ((rc = pass(terms0, RangeGate{guarded ? flag : nullptr, 0}))) return rc;
         if (guarded) {
             if ((rc = pass(RANGE_FREE_MODE, RangeGate{flag, 1}))) return rc;
             HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned), h->side));
         }
-        HIP_TRY(hipEventRecord(h->ev_join[k & 1], h->side));
+        HIP_TRY(hipEventRecord(h->ev_join[k % RING], h->side));
     }
-    if (piped) HIP_TRY(hipStreamWaitEvent(s_main, h->ev_join[(k - 1) & 1], 0));
+    if (piped) HIP_TRY(hipStreamWaitEvent(s_main, h->ev_join[(k - 1) % RING], 0));
     return KWS_OK;
 }
 
@@ -1480,7 +1485,7 @@ int kws_create(const kws_model_desc* desc, kws_handle** out) {
             HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
             HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_greatest));
             // the events order two streams of ONE device: no system-scope fence (an L2 write-back per record, ~8 us between conv_band and the next conv_in1)
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < kws_handle::CNN_RING; ++i) {
                 HIP_TRY(hipEventCreateWithFlags(&h->ev_fork[i], hipEventDisableTiming | hipEventDisableSystemFence));
                 HIP_TRY(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming | hipEventDisableSystemFence));
             }

@@ -526,6 +526,7 @@ struct ColsConvParams {
     float inv_scale;             // 2^-S of the weights
     int relu, out_f16;
     RangeGate rg;
+    unsigned* queue;             // two device words, zero between launches (kws_internal.h, queue_retire): the unit counter
     unsigned long long* dbg_ts;  // KWS_BAND_TIMING (with a -DCOLS_TIMING build): phase stamps of the first 512 workgroups' units, or nullptr
 };
 bool conv_cols_supported(int Cin, int Cout, int H, int W, int kh, int kw);
