@@ -7,16 +7,16 @@
 //
 //   * a position tile = 16 consecutive output ROWS of one output COLUMN x (lane = row).  The B fragment of tile x for tap (dy, dx) and channel quad cq is
 //     the 16 cells (row + dy, x + dx) -- a function of the input column c = x + dx alone: one fragment F(c) per (dy, cq) sweep serves kw = 4 taps of up to
-//     four tiles.  A wave owns MH channel tiles x NX <= 7 columns: per sweep NX + 3 LDS reads and 4 MH weight fragments feed 4 MH NX MFMAs (56 for
-//     cnn-trad-pool2: 5.6 MFMAs per LDS read instead of 2; every one of the 32 x 13 outputs sits in a tile: 1 120 MFMAs per wave and band instead of 1 280);
-//   * workgroups of four waves (wave = channel half x column half), TWO per CU, each persistent over (clip, band) units drawn from a device-wide counter,
+//     four tiles.  A wave owns ONE channel tile and ALL Wo <= 14 columns: per sweep Wo + 3 LDS reads and 4 weight fragments feed 4 Wo MFMAs (cnn-trad-pool2: 52
+//     MFMAs per 16 LDS reads and 4 KB of weights, where conv_band_kernel's wave reads 8 + 2 KB per 16; every one of the 32 x 13 outputs sits in a tile:
+//     1 040 MFMAs per wave and band instead of 1 280);
+//   * workgroups of four waves (one per channel tile), TWO per CU, each persistent over (clip, band) units drawn from a device-wide counter,
 //     with ONE LDS image: the next unit's 25 input rows are requested with global_load_lds_dwordx4 (memory -> LDS, no registers) once every wave has left the
 //     k-loop and land while the epilogue runs -- and while the CU's other workgroup computes.  (The first version, one double-buffered workgroup per CU, ran
 //     its 1 120 MFMAs per unit in 30 k cycles with every load ablated: a lone wave per SIMD does not reach the pipe's rate.)  The image is four planes, one per
 //     lane group, rows an odd number of 16-byte slots apart: fragment reads without bank conflicts (cols_image_bytes); the DMA fills it in any order it likes,
 //     since every lane names its own 16 source bytes;
-//   * one set of fragment registers, refilled in place a sweep ahead; two sets of weight fragments, all of the next sweep's requested in front of this
-//     sweep's first tile; a tile's four taps as one chain on its accumulator (cols_kloop).
+//   * one set of fragment registers, refilled in place a sweep ahead; four sets of weight fragments, requested two sweeps ahead; a tile's four taps as one chain on its accumulator (cols_kloop).
 //
 // in: channels-last fp16 cells (B, H, W, Cpi = 64); out: channels-last (B, Ho, Wo, Cpo) fp16 or fp32 cells, exact zeros in the channel padding; weights
 // x 2^S as fp16 fragments in sweep order (pack_conv_cols_weights).  Same products in a different summation order than conv_band_kernel (K runs (dy, cq, dx)
@@ -39,23 +39,25 @@ __device__ __forceinline__ u32x4 cols_lds_read16(int addr) { return *reinterpret
 #endif
 constexpr int COLS_KW = 4;
 constexpr int COLS_ROWS = 16;      // output rows per band = lanes of a position tile
+constexpr int COLS_MT = 4;         // channel tiles of the layer = waves of a workgroup (49 - 64 output channels)
+constexpr int COLS_NXMAX = 14;     // output columns (tiles per wave)
 
 // The k-loop of a wave that owns NXW output columns (x0 .. x0 + NXW - 1) and MH channel tiles; CB = bytes per cell, NQ = channel quads per cell.
 // Sweep t = dy * NQ + cq; fragment c of sweep t is read at fbase + dy * rsb + cq * 16 + c * NQ * 16 (plane g of the image, cols_image_bytes).  ONE set of NC fragment registers: column c's register is
 // refilled with the next sweep's column c as soon as this sweep's MFMAs on it are issued (a sweep -- ~900 cycles -- ahead of its use); the weight fragments
-// have two sets (a fragment's last use in a sweep is only ~4 columns before its first use in the next: less than an L2 round trip).
+// have four sets, requested two sweeps ahead.  In: a0 / a1 = the weights of sweeps 0 / 1 (requested, maybe in flight); out: the same for the next unit.
 template <int MH, int NXW, int CB, int NQ>
 __device__ __forceinline__ void cols_kloop(const __amdgpu_buffer_rsrc_t ars, const int avoff, const int fbase, const int rsb, const int kh,
-                                           f32x4 (&acc)[MH][7], u32x4 (&a0)[COLS_KW][MH]) {
+                                           f32x4 (&acc)[MH][COLS_NXMAX], u32x4 (&a0)[COLS_KW][MH], u32x4 (&a1)[COLS_KW][MH]) {
     constexpr int NC = NXW + COLS_KW - 1;
     constexpr int FS = NQ * 16;                           // bytes between the fragments of neighbouring columns in an LDS plane
-    constexpr int ASWEEP_B = COLS_KW * 2 * MH * 1024;     // bytes of weight fragments per sweep: [dx][2 MH channel tiles][64 lanes] x 16 B
+    constexpr int ASWEEP_B = COLS_KW * COLS_MT * 1024;    // bytes of weight fragments per sweep: [dx][4 channel tiles][64 lanes] x 16 B
     const int nsweep = kh * NQ;
-    u32x4 a1[COLS_KW][MH], f[NC];
+    u32x4 f[NC];
     // (sweep numbers are wave-uniform, but hipcc does not always see it: a scalar offset it takes for a vector costs a waterfall loop around every load)
     auto load_a = [&](u32x4 (&ar)[COLS_KW][MH], int i, int so) {      // fragment i = dx * MH + m of the sweep whose fragments start at byte so
         const int dx = i / MH, m = i - dx * MH;
-        ar[dx][m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff + (dx * 2 * MH + m) * 1024, so, 0));
+        ar[dx][m] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff + (dx * COLS_MT + m) * 1024, so, 0));
     };
     auto faddr = [&](int t) {
         const int dy = t / NQ, cq = t - dy * NQ;
@@ -101,18 +103,17 @@ __device__ __forceinline__ void cols_kloop(const __amdgpu_buffer_rsrc_t ars, con
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int t = 0; t < nsweep; t += 2) {
-        // (past the last sweep: the weights of sweep 0 -- the next unit's first -- and a harmless re-read of the image)
-        const int t1 = t + 1 < nsweep ? t + 1 : t, t2 = t + 2 < nsweep ? t + 2 : t1;
-        sweep(a0, a1, t + 1 < nsweep ? t + 1 : 0, faddr(t1));
-        if (t + 1 >= nsweep) {      // odd sweep count: the weights for the next unit sit in a1
-#pragma unroll
-            for (int dx = 0; dx < COLS_KW; ++dx)
-#pragma unroll
-                for (int m = 0; m < MH; ++m) a0[dx][m] = a1[dx][m];
-            break;
-        }
-        sweep(a1, a0, t + 2 < nsweep ? t + 2 : 0, faddr(t2));
+    // Four weight sets, requested two sweeps ahead (an L2 round trip under load is longer than one sweep: with two sets, one sweep ahead, the loop spent 18 % of
+    // its time waiting for weights, -DCOLS_ABLATE=1).  The sweep count is a multiple of four (conv_cols_supported); past the last sweep the requests wrap to
+    // the next unit's first two, which are back in a0 / a1 then.
+    u32x4 b0[COLS_KW][MH], b1[COLS_KW][MH];
+    auto wrap = [&](int t) { return t < nsweep ? t : t - nsweep; };
+    auto fwrap = [&](int t) { return faddr(t < nsweep ? t : nsweep - 1); };
+    for (int t = 0; t < nsweep; t += 4) {
+        sweep(a0, b0, t + 2, fwrap(t + 1));
+        sweep(a1, b1, t + 3, fwrap(t + 2));
+        sweep(b0, a0, wrap(t + 4), fwrap(t + 3));
+        sweep(b1, a1, wrap(t + 5), fwrap(t + 4));
     }
 }
 }  // namespace
@@ -136,7 +137,6 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w & 1, wn = w >> 1;
     const int g = lane >> 4, pcol = lane & 15;
     const int rb = p.W * CB;                   // bytes per input row in memory
     const int slr = cols_row_slots(p.W, CPI16 * 16), rsb = slr * 16;      // slots / bytes per row of an LDS plane
@@ -182,10 +182,9 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
     dma_unit(u_begin);
 
     // this wave's columns: the first half of the Wo output columns or the rest
-    const int nx0 = (p.Wo + 1) >> 1;
-    const int x0 = wn ? nx0 : 0, nxw = wn ? p.Wo - nx0 : nx0;
-    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk), 0, p.kh * NQ * (COLS_KW * 2 * MH * 1024), 0x00020000);
-    const int avoff = lane * 16 + (wm * MH) * 1024;
+    const int x0 = 0, nxw = p.Wo;              // (every wave takes all columns; an earlier split -- channel halves x column halves -- loaded every weight fragment twice per workgroup: 116 -> 106 us)
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk), 0, p.kh * NQ * (COLS_KW * COLS_MT * 1024), 0x00020000);
+    const int avoff = lane * 16 + w * MH * 1024;
     const int fbase = g * ps * 16 + pcol * rsb + x0 * (NQ * 16);
     float amax = 0.f;
     f32x4 bias_v[MH];      // (loaded here, not in the epilogue: a load there waits for the image pieces requested just before it -- vmcnt counts in order)
@@ -193,13 +192,15 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
     for (int m = 0; m < MH; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int co = (wm * MH + m) * 16 + 4 * g + r;
+            const int co = (w * MH + m) * 16 + 4 * g + r;
             bias_v[m][r] = co < p.Cout ? p.bias[co] : 0.f;
         }
-    u32x4 a0[COLS_KW][MH];
+    u32x4 a0[COLS_KW][MH], a1[COLS_KW][MH];
 #pragma unroll
-    for (int i = 0; i < COLS_KW * MH; ++i)
-        a0[i / MH][i % MH] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff + ((i / MH) * 2 * MH + i % MH) * 1024, 0, 0));
+    for (int i = 0; i < COLS_KW * MH; ++i) {
+        a0[i / MH][i % MH] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff + ((i / MH) * COLS_MT + i % MH) * 1024, 0, 0));
+        a1[i / MH][i % MH] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff + ((i / MH) * COLS_MT + i % MH) * 1024, COLS_KW * COLS_MT * 1024, 0));
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -213,14 +214,14 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
     for (int u = u_begin, nu = 0; u < nunit; u = nu) {
         COLS_TS(0)
         if (tid == 0) *next_slot = (int)(gridDim.x + atomicAdd(p.queue, 1u));      // the unit after this one: known to everyone behind the k-loop's barrier
-        f32x4 acc[MH][7];
+        f32x4 acc[MH][COLS_NXMAX];
 #pragma unroll
         for (int m = 0; m < MH; ++m)
 #pragma unroll
-            for (int x = 0; x < 7; ++x) acc[m][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#define COLS_CASE(N) case N: cols_kloop<MH, N, CB, NQ>(ars, avoff, fbase, rsb, p.kh, acc, a0); break;
+            for (int x = 0; x < COLS_NXMAX; ++x) acc[m][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define COLS_CASE(N) case N: cols_kloop<MH, N, CB, NQ>(ars, avoff, fbase, rsb, p.kh, acc, a0, a1); break;
         switch (nxw) {
-            COLS_CASE(7) COLS_CASE(6) COLS_CASE(5) COLS_CASE(4) COLS_CASE(3) COLS_CASE(2) COLS_CASE(1)
+            COLS_CASE(14) COLS_CASE(13) COLS_CASE(12) COLS_CASE(11) COLS_CASE(10) COLS_CASE(9) COLS_CASE(8) COLS_CASE(7) COLS_CASE(6) COLS_CASE(5) COLS_CASE(4)
             default: break;
         }
 #undef COLS_CASE
@@ -237,11 +238,11 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
         const size_t obase = ((size_t)b * p.Ho + r0 + pcol) * p.Wo + x0;
 #pragma unroll
         for (int m = 0; m < MH; ++m) {
-            const int co0 = (wm * MH + m) * 16 + 4 * g;
+            const int co0 = (w * MH + m) * 16 + 4 * g;
             if (co0 >= p.Cpo) continue;
             const f32x4 bv = bias_v[m];
 #pragma unroll
-            for (int x = 0; x < 7; ++x) {
+            for (int x = 0; x < COLS_NXMAX; ++x) {
                 if (x >= nxw) continue;
                 f32x4 v;
 #pragma unroll
@@ -278,19 +279,19 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
     range_note(p.rg, amax);
 }
 
-// the layer fits: four kernel columns, 64 input channels, up to 64 output channels (three channel tiles per wave would spill), up to 14 output columns, at least one full band of rows, both images in LDS
+// the layer fits: four kernel columns, 64 input channels, a multiple of four sweeps (an even number of kernel rows), four tiles of output channels, 4 .. 14 output columns, at least one full band of rows, both images in LDS
 bool conv_cols_supported(int Cin, int Cout, int H, int W, int kh, int kw) {
-    const int Cpi = (Cin + 15) / 16 * 16, Ho = H - kh + 1, Wo = W - kw + 1, mh = conv_band_mh(Cout);
-    if (kw != COLS_KW || Cpi != 64 || mh != 2 || Wo < 2 || Wo > 14 || Ho < COLS_ROWS) return false;
+    const int Cpi = (Cin + 15) / 16 * 16, Ho = H - kh + 1, Wo = W - kw + 1;
+    if (kw != COLS_KW || Cpi != 64 || (kh * ((Cpi + 31) / 32)) % 4 || (Cout + 15) / 16 != COLS_MT || Wo < 4 || Wo > COLS_NXMAX || Ho < COLS_ROWS) return false;
     if (cols_lds_bytes(W, Cpi, kh) > 80 * 1024 - 256) return false;      // two workgroups per CU
     // rows computed / rows needed (the last band overlaps the one before it): not below 0.85
     const int nb = (Ho + COLS_ROWS - 1) / COLS_ROWS;
     return (double)Ho / (nb * COLS_ROWS) >= 0.85;
 }
 
-// weights (Cout, Cin, kh, 4) x scale -> fp16, [dy][cq][dx][2 MH channel tiles][lane][8]; lane = (g << 4) | co, slot e of lane group g = channel (4 cq + g) 8 + e
+// weights (Cout, Cin, kh, 4) x scale -> fp16, [dy][cq][dx][4 channel tiles][lane][8]; lane = (g << 4) | co, slot e of lane group g = channel (4 cq + g) 8 + e
 void pack_conv_cols_weights(int Cin, int Cout, int kh, const float* w, float scale, std::vector<unsigned short>& dst) {
-    const int Cpi = (Cin + 15) / 16 * 16, nq = (Cpi + 31) / 32, mtt = 2 * conv_band_mh(Cout);
+    const int Cpi = (Cin + 15) / 16 * 16, nq = (Cpi + 31) / 32, mtt = COLS_MT;
     dst.assign((size_t)kh * nq * COLS_KW * mtt * 64 * 8, 0);
     for (int dy = 0; dy < kh; ++dy)
         for (int cq = 0; cq < nq; ++cq)
@@ -307,9 +308,8 @@ void pack_conv_cols_weights(int Cin, int Cout, int kh, const float* w, float sca
                     }
 }
 
-template <int MH>
-static hipError_t launch_cols_mh(const ColsConvParams& p, int n_cu, hipStream_t s) {
-    auto k = conv_cols_kernel<MH, 4>;
+static hipError_t launch_cols_k(const ColsConvParams& p, int n_cu, hipStream_t s) {
+    auto k = conv_cols_kernel<1, 4>;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
         hipError_t e = allow_big_lds_at_base_zero(reinterpret_cast<const void*>(k));
@@ -323,11 +323,10 @@ static hipError_t launch_cols_mh(const ColsConvParams& p, int n_cu, hipStream_t 
 
 hipError_t launch_conv_cols(const ColsConvParams& p, int n_cu, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
-    const int mh = conv_band_mh(p.Cout);
-    if (!p.queue || p.Cpi != 64 || mh != 2 || p.Cpo % 16 || p.Cpo < p.Cout || p.Cpo > 32 * mh || p.Ho != p.H - p.kh + 1 || p.Wo != p.W - COLS_KW + 1 || p.Wo > 14 || p.Ho < COLS_ROWS ||
+    if (!p.queue || p.Cpi != 64 || (p.kh * 2) % 4 || (p.Cout + 15) / 16 != COLS_MT || p.Cpo % 16 || p.Cpo < p.Cout || p.Cpo > 16 * COLS_MT || p.Ho != p.H - p.kh + 1 || p.Wo != p.W - COLS_KW + 1 || p.Wo < 4 || p.Wo > COLS_NXMAX || p.Ho < COLS_ROWS ||
         p.nbands != (p.Ho + COLS_ROWS - 1) / COLS_ROWS || cols_lds_bytes(p.W, p.Cpi, p.kh) > 80 * 1024 - 256)
         return hipErrorInvalidValue;
-    return launch_cols_mh<2>(p, n_cu, s);
+    return launch_cols_k(p, n_cu, s);
 }
 
 }  // namespace kws
