@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.apk), 0, p.kh * NQ * (COLS_KW * COLS_MT * 1024), 0x00020000);
     const int avoff = lane * 16 + w * MH * 1024;
     const int fbase = g * ps * 16 + pcol * rsb + x0 * (NQ * 16);
-    float amax = 0.f;
+    unsigned amax_u = 0u;
+    const float relu_lo = p.relu ? 0.f : -INFINITY;      // ReLU as one maximum, no select
     f32x4 bias_v[MH];      // (loaded here, not in the epilogue: a load there waits for the image pieces requested just before it -- vmcnt counts in order)
 #pragma unroll
     for (int m = 0; m < MH; ++m)
@@ -246,11 +247,11 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
                 if (x >= nxw) continue;
                 f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float y = fmaf(acc[m][x][r], p.inv_scale, bv[r]);
-                    if (p.relu) y = fmaxf(y, 0.f);
-                    v[r] = co0 + r < p.Cout ? y : 0.f;
-                    amax = fmaxf(amax, fabsf(v[r]));
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc[m][x][r], p.inv_scale, bv[r]), relu_lo);      // (channels past Cout: zero weights, zero bias -> the exact zero the padding holds)
+                {
+                    const float s0 = v[0], s1 = v[1], s2 = v[2], s3 = v[3];      // largest magnitude as a bit pattern (a NaN sorts above every number), two values per v_max3_u32
+                    amax_u = max(max(amax_u, __builtin_bit_cast(unsigned, s0) & 0x7fffffffu), __builtin_bit_cast(unsigned, s1) & 0x7fffffffu);
+                    amax_u = max(max(amax_u, __builtin_bit_cast(unsigned, s2) & 0x7fffffffu), __builtin_bit_cast(unsigned, s3) & 0x7fffffffu);
                 }
                 if (!row_ok) continue;
                 const size_t o = (obase + x) * p.Cpo + co0;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv_cols_kernel(ColsConvParams p) {
 #endif
     }
     if (tid == 0) queue_retire(p.queue);
-    range_note(p.rg, amax);
+    range_note(p.rg, __builtin_bit_cast(float, amax_u));
 }
 
 // the layer fits: four kernel columns, 64 input channels, a multiple of four sweeps (an even number of kernel rows), four tiles of output channels, 4 .. 14 output columns, at least one full band of rows, both images in LDS

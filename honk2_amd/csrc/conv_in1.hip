@@ -120,8 +120,9 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
     const int ngroup = (p.mtiles + MH - 1) / MH;
     const u32x4* A = reinterpret_cast<const u32x4*>(p.apk) + lane;   // [group][k-step][MH][2 parts][64]
     const int kstep_b = 4 * RS * 2;              // bytes per k-step (four feature rows)
-    float amax = 0.f;
+    unsigned amax_u = 0u;
     const float pinf = opaque_pinf();
+    const float relu_lo = p.relu ? 0.f : -INFINITY;      // ReLU as one maximum, no select
 
     for (int cg = 0; cg < ngroup; ++cg) {
         u32x4 a[KS][MH][NP];
@@ -187,9 +188,13 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x = fmaf(best[m][r], p.inv_scale, bv[m][r]);   // 2^-S > 0 commutes with the maximum
-                    if (p.relu) x = fmaxf(x, 0.f);
-                    v[r] = co0 + r < p.Cout ? x : 0.f;
-                    amax = fmaxf(amax, fabsf(v[r]));
+                    v[r] = fmaxf(x, relu_lo);      // (channels past Cout: zero weights and a zero bias give the exact zero the padding must hold)
+                }
+                // largest magnitude as a bit pattern (orders like the magnitudes; a NaN sorts above every number and flags the chunk): two values per v_max3_u32
+                {
+                    const float s0 = v[0], s1 = v[1], s2 = v[2], s3 = v[3];      // (a bit cast of a vector ELEMENT reads element 0: scalars first)
+                    amax_u = max(max(amax_u, __builtin_bit_cast(unsigned, s0) & 0x7fffffffu), __builtin_bit_cast(unsigned, s1) & 0x7fffffffu);
+                    amax_u = max(max(amax_u, __builtin_bit_cast(unsigned, s2) & 0x7fffffffu), __builtin_bit_cast(unsigned, s3) & 0x7fffffffu);
                 }
                 if (p.out_f16) {
                     const u32x2 pk = {__builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[0], v[1]}, f16x2)),
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
             }
         }
     }
-    range_note(p.rg, amax);
+    range_note(p.rg, __builtin_bit_cast(float, amax_u));
 }
 
 size_t conv_in1_lds_bytes(int T, int F, int parts) { return (size_t)parts * 4 * in1_copy_bytes(T, F) + IN1_TAIL; }
