@@ -1236,7 +1236,13 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
                     if (rcz) return rcz;
                     bp.dbg_ts = band_buf.as<unsigned long long>();
                 }
-                if (h->cnn_cols && m_terms == 1 && h->cconv[1].apk_cols.p) {
+                const bool cols_this = h->cnn_cols && m_terms == 1 && h->cconv[1].apk_cols.p;
+                const int detail_code = -2 - ((h->cnn_in1 ? 1 : 0) | (cols_this ? 2 : 0) | (piped ? 4 : 0));      // (plan_detail_T of a cnn handle: which of the eight texts it holds)
+                if (b0 == 0 && !rg.gated && h->plan_detail_T != detail_code) {
+                    h->plan_detail = std::string(h->cnn_in1 ? "conv_in1" : "conv_0") + (cols_this ? " conv_cols" : " conv_band") + " linear" + (piped ? " | two streams" : "");
+                    h->plan_detail_T = detail_code;
+                }
+                if (cols_this) {
                     ColsConvParams cp{};
                     cp.in = reinterpret_cast<const unsigned short*>(bp.in); cp.out = bp.out;
                     cp.apk = h->cconv[1].apk_cols.as<unsigned short>(); cp.bias = bp.bias;
@@ -1822,7 +1828,8 @@ int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target
 const char* kws_plan_name(const kws_handle* h) { return h ? h->last_plan : "none"; }
 const char* kws_plan_detail(const kws_handle* h) {
     if (!h) return "none";
-    return (h->last_plan && std::strcmp(h->last_plan, "resnet_tiled") == 0 && !h->plan_detail.empty()) ? h->plan_detail.c_str() : h->last_plan;
+    const bool detailed = h->last_plan && (std::strcmp(h->last_plan, "resnet_tiled") == 0 || std::strcmp(h->last_plan, "cnn_band") == 0 || std::strcmp(h->last_plan, "cnn_in1") == 0);
+    return (detailed && !h->plan_detail.empty()) ? h->plan_detail.c_str() : h->last_plan;
 }
 
 int kws_profile_enable(kws_handle* h, int enable) {

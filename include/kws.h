@@ -186,9 +186,9 @@ int kws_eval_batch(kws_handle* h, const float* d_logits, const int64_t* d_target
 
 /* Which execution plan the handle uses, e.g. "res8_fused" or "layerwise". */
 const char* kws_plan_name(const kws_handle* h);
-/* What the last kws_forward* call launched per chunk on the tiled ResNet plan, layer by layer -- e.g. "conv0 pair(1,2) conv(3)
- * triple(4,5,6) triple(7,8,9) triple(10,11,12) conv(13) mean+linear" -- or the plan name on the other plans (diagnostics and tests; the
- * pointer stays valid until the next compute call on the handle). */
+/* What the last kws_forward* call launched per chunk on the tiled ResNet plan, layer by layer -- e.g. "conv0 stream(1,2,3) stream(4,5,6)
+ * stream(7,8,9) stream(10,11,12) stream(13) mean+linear" --, on the cnn band plan -- e.g. "conv_in1 conv_cols linear | two streams" --, or the
+ * plan name on the other plans (diagnostics and tests; the pointer stays valid until the next compute call on the handle). */
 const char* kws_plan_detail(const kws_handle* h);
 
 /* Optional in-library timing of the dominant kernel: when enabled every kws_forward* call brackets the model

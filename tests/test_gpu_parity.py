@@ -307,6 +307,16 @@ _ODD_CNNS = {
                       "conv_0": {"out_channels": 20, "kernel_size": [12, 8], "stride": [1, 1]}, "pool_0": {"kernel_size": [2, 2]},
                       "conv_1": {"out_channels": 40, "kernel_size": [5, 5], "stride": [1, 1]}, "pool_1": {"kernel_size": [1, 1]},
                       "lin_0": {"out_features": 24}}, "cnn_band"),
+    # conv_cols.hip off its shipped shape: 64 -> 50 channels (four tiles, the last one padded), eight kernel rows (16 sweeps), a 36 x 11 map -> 29 x 8 outputs:
+    # two bands of 16 rows, the second moved up to end on the last row (three of its rows belong to the first)
+    "cols_two_bands": ({"time": 88, "frequency": 40, "dropout_prob": 0.5, "n_labels": 6,
+                        "conv_0": {"out_channels": 64, "kernel_size": [16, 8], "stride": [1, 1]}, "pool_0": {"kernel_size": [2, 3]},
+                        "conv_1": {"out_channels": 50, "kernel_size": [8, 4], "stride": [1, 1]}, "pool_1": {"kernel_size": [1, 1]},
+                        "lin_0": {"out_features": 24}}, "cnn_band"),
+    # ... and at its widest: 14 output columns, exactly one band of 16 rows, twelve kernel rows
+    "cols_wide": ({"time": 68, "frequency": 60, "dropout_prob": 0.5, "n_labels": 9,
+                   "conv_0": {"out_channels": 60, "kernel_size": [16, 8], "stride": [2, 1]}, "pool_0": {"kernel_size": [1, 3]},
+                   "conv_1": {"out_channels": 64, "kernel_size": [12, 4], "stride": [1, 1]}, "pool_1": {"kernel_size": [1, 1]}}, "cnn_band"),
     # strided conv_1: no band plan, nothing channels-last
     "strided_conv1": ({"time": 101, "frequency": 40, "dropout_prob": 0.5, "n_labels": 12,
                        "conv_0": {"out_channels": 32, "kernel_size": [20, 8], "stride": [1, 1]}, "pool_0": {"kernel_size": [2, 2]},
@@ -336,6 +346,8 @@ def test_cnn_geometries_beyond_the_shipped_configs(torch_cuda, case, dtype):
     model = _build(torch, "CNN", dict(cfg, dtype=dtype), sd)
     got = model(torch.from_numpy(feats).cuda()).cpu().numpy()
     assert model.plan_name() == plan
+    if case.startswith("cols"):      # (`fp16` tensors: the column-tile kernel; f32: three-term products stay on conv_band.hip)
+        assert ("conv_cols" in model.plan_detail()) == (dtype == "fp16"), model.plan_detail()
     want = models.forward_torch("CNN", cfg, sd, feats).numpy()
     tol = LOGIT_TOL if dtype == "f32" else 5e-3 * max(1.0, float(np.abs(want).max()))
     assert np.abs(got - want).max() < tol, (case, dtype, np.abs(got - want).max())
@@ -1596,3 +1608,31 @@ def test_cnn_two_stream_chunks_change_no_bit(torch_cuda, monkeypatch, fname, dty
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, w), float((out - w).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", ["model_cnn__cnn-trad-pool2.npz", "model_cnn__cnn-trad-fpool3.npz"])
+def test_column_tile_conv_1_agrees_with_the_band_kernel(torch_cuda, monkeypatch, fname):
+    """`fp16` dtype, conv_1 of the two shipped configs it fits (reference model/cnn.py:82-92): conv_cols.hip forms the same single-term fp16 products as
+    conv_band.hip and sums them in another order (kernel row, channel quad, kernel column instead of tap, channel block) -- so over 1 100 clips (a ragged second
+    chunk, two streams) the two must agree to fp32 rounding of the accumulations, far inside the fp16 bar both are held to against the oracle, and a clip's
+    logits must not depend on its neighbours or on which workgroup drew its bands."""
+    torch = torch_cuda
+    from oracle import models, weights
+    tag, name, cfg, sd, feats, z = load_golden_model(fname)
+    f = weights.make_features(1100, seed=51)
+    x = torch.from_numpy(f).cuda()
+    cols = _build(torch, name, dict(cfg, dtype="fp16"), sd)
+    got = cols(x)
+    assert "conv_cols" in cols.plan_detail() and "two streams" in cols.plan_detail(), cols.plan_detail()
+    monkeypatch.setenv("KWS_CNN_COLS", "0")
+    band = _build(torch, name, dict(cfg, dtype="fp16"), sd)
+    ref = band(x)
+    assert "conv_band" in band.plan_detail(), band.plan_detail()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) < 2e-4 * scale, float((got - ref).abs().max())
+    want = models.forward_torch(name, cfg, sd, f[:300]).numpy()
+    assert np.abs(got[:300].cpu().numpy() - want).max() < 5e-3 * max(1.0, float(np.abs(want).max()))
+    for _ in range(2):                                   # the unit counter hands bands out in a different order every launch
+        assert torch.equal(cols(x), got)
+    assert torch.equal(cols(x[37:300]), got[37:300])     # ... and a clip's logits do not depend on where it sits in the batch
