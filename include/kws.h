@@ -34,6 +34,9 @@
  *     first time a LARGER batch arrives -- the outgrown block is kept until kws_destroy, because a graph
  *     captured at the smaller size still names it.  A call that would have to allocate while `stream` is
  *     being captured returns KWS_ENOWORKSPACE instead of allocating.
+ *     (A cnn-* handle owns a second stream: a kws_forward* call of more than one chunk forks part of each chunk's work
+ *     onto it with events and has joined it again before the call returns -- ordered on `stream` at both ends, no host
+ *     synchronisation, captured along with the call; kernel and event nodes then.  KWS_CNN_STREAMS=0 at kws_create: off.)
  *   - LIFETIME UNDER GRAPHS: every buffer baked into a captured graph -- the caller's input / output
  *     buffers, the workspace given to kws_set_workspace, and the handle itself (weights, tables, queue
  *     words) -- must outlive every replay of that graph.  Synchronise with the replaying stream before
@@ -57,7 +60,7 @@
  *   - Environment: the library reads a few IMPLEMENTATION SELECTORS at kws_create (or per call where noted), each choosing between
  *     implementations that are parity-tested against the same oracle -- KWS_RES8_IMPL=bf16x6|fp32, KWS_FRONTEND_IMPL=fp32,
  *     KWS_LAYERWISE_IMPL=nchw|fp32, KWS_FORCE_LAYERWISE=1, KWS_MATRIX_PARTS=bf16 (per call), KWS_CNN_BAND=0, KWS_CNN_IN1=0,
- *     KWS_CNN_LIN_F16=0, KWS_T3_PAIR=0, KWS_T3_TRIPLE=0|2, KWS_T3_STREAM=0|2|3, KWS_WINDOWS_NO_SHARE (per call) -- and NOTHING ELSE: the ablation bits,
+ *     KWS_CNN_LIN_F16=0, KWS_CNN_COLS=0, KWS_CNN_STREAMS=0, KWS_T3_PAIR=0, KWS_T3_TRIPLE=0|2, KWS_T3_STREAM=0|2|3, KWS_WINDOWS_NO_SHARE (per call) -- and NOTHING ELSE: the ablation bits,
  *     phase stamps, grid-size knobs and the fault-injection hook of the measurement rig exist only in `make EXPERIMENTS=1`
  *     (libkws_hip_exp.so); no environment variable can make this library compute wrong results, synchronise inside a compute
  *     call or throw.
