@@ -50,7 +50,7 @@ def source_digest(rel):
         return None
 
 
-PMC_SUMMARIES = ("profiles/r04/final_summary.json", "profiles/r04/v12_summary.json", "profiles/r03/final_summary.json", "profiles/r03/v11_summary.json", "profiles/r02/final_summary.json")   # newest first
+PMC_SUMMARIES = ("profiles/r05/final_summary.json", "profiles/r04/final_summary.json", "profiles/r04/v12_summary.json", "profiles/r03/final_summary.json", "profiles/r03/v11_summary.json", "profiles/r02/final_summary.json")   # newest first
 
 
 SYNTH_BLOCK = 1024
