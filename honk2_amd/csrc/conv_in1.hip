@@ -51,8 +51,9 @@ __host__ __device__ inline int in1_copy_bytes(int T, int F) {
     return (raw + IN1_COPY_ALIGN - 1 - IN1_COPY_SKEW) / IN1_COPY_ALIGN * IN1_COPY_ALIGN + IN1_COPY_SKEW;
 }
 
-// KS: k-steps (ceil(kh / 4)); MH: channel tiles per pass; TERMS: 3 (two-part operands) or 1 (fp16 products, fp16 cells out)
-template <int KS, int MH, int TERMS>
+// KS: k-steps (ceil(kh / 4)); MH: channel tiles per pass; TERMS: 3 (two-part operands) or 1 (fp16 products, fp16 cells out); FC: the map's width when it is
+// the 40 mel bands of every shipped config (the k-steps' LDS offsets become immediates of the fragment reads), 0: any width
+template <int KS, int MH, int TERMS, int FC>
 __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
     constexpr int NP = TERMS >= 3 ? 2 : 1;
     extern __shared__ __align__(16) char lds[];
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, pcol = lane & 15;
     const int b = blockIdx.x;
-    const int RS = p.F + 4;                      // row stride in halfs
+    const int RS = FC ? FC + 4 : p.F + 4;        // row stride in halfs
     const int copyb = in1_copy_bytes(p.T, p.F);
     const int partb = 4 * copyb;
 
@@ -120,7 +121,9 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
     const int ngroup = (p.mtiles + MH - 1) / MH;
     const u32x4* A = reinterpret_cast<const u32x4*>(p.apk) + lane;   // [group][k-step][MH][2 parts][64]
     const int kstep_b = 4 * RS * 2;              // bytes per k-step (four feature rows)
-    unsigned amax_u = 0u;
+    float amax = 0.f;
+    const int step_y = 64 / p.Wq, step_x = 64 - step_y * p.Wq;      // four waves x 16 positions between a wave's tiles
+    const int row_step_b = p.sh * RS * 2;
     const float pinf = opaque_pinf();
     const float relu_lo = p.relu ? 0.f : -INFINITY;      // ReLU as one maximum, no select
 
@@ -140,17 +143,24 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
                 const int co = (cg * MH + m) * 16 + 4 * g + r;
                 bv[m][r] = co < p.Cout ? p.bias[co] : 0.f;
             }
-        for (int t = w; t < ntile; t += 4) {
+        // this lane's pooled position of tile t: (oy, ox) walks 64 positions per tile of the wave (one division per channel group, not one per tile)
+        int oy = (w * 16 + pcol) / p.Wq, ox = (w * 16 + pcol) - oy * p.Wq;
+        for (int t = w; t < ntile; t += 4, oy += step_y, ox += step_x) {
+            if (ox >= p.Wq) {
+                ox -= p.Wq;
+                ++oy;
+            }
             const int ps = t * 16 + pcol;
-            const int pc = min(ps, npq - 1);
-            const int oyq = pc / p.Wq, oxq = pc - oyq * p.Wq;
+            const bool inside = ps < npq;                       // (lanes past the map compute its last position and store nothing)
+            const int oyq = inside ? oy : p.Hq - 1, oxq = inside ? ox : p.Wq - 1;
+            const int rowb0 = (oyq * p.ph * p.sh + g) * (RS * 2), xb0 = oxq * p.pw * p.sw;
             f32x4 best[MH];
 #pragma unroll
             for (int m = 0; m < MH; ++m) best[m] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             for (int dy = 0; dy < p.ph; ++dy)
             for (int dx = 0; dx < p.pw; ++dx) {
-                const int row = (oyq * p.ph + dy) * p.sh + g, x0 = (oxq * p.pw + dx) * p.sw;
-                const char* bp = lds + (x0 & 3) * copyb + (row * RS + (x0 & ~3)) * 2;
+                const int x0 = xb0 + dx * p.sw;
+                const char* bp = lds + (x0 & 3) * copyb + (x0 & ~3) * 2 + rowb0 + dy * row_step_b;
                 f32x4 acc[MH];
 #pragma unroll
                 for (int m = 0; m < MH; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -190,12 +200,10 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
                     float x = fmaf(best[m][r], p.inv_scale, bv[m][r]);   // 2^-S > 0 commutes with the maximum
                     v[r] = fmaxf(x, relu_lo);      // (channels past Cout: zero weights and a zero bias give the exact zero the padding must hold)
                 }
-                // largest magnitude as a bit pattern (orders like the magnitudes; a NaN sorts above every number and flags the chunk): two values per v_max3_u32
-                {
-                    const float s0 = v[0], s1 = v[1], s2 = v[2], s3 = v[3];      // (a bit cast of a vector ELEMENT reads element 0: scalars first)
-                    amax_u = max(max(amax_u, __builtin_bit_cast(unsigned, s0) & 0x7fffffffu), __builtin_bit_cast(unsigned, s1) & 0x7fffffffu);
-                    amax_u = max(max(amax_u, __builtin_bit_cast(unsigned, s2) & 0x7fffffffu), __builtin_bit_cast(unsigned, s3) & 0x7fffffffu);
-                }
+                // largest magnitude, two values per v_max3_f32 (|x| is an input modifier; values straight out of an FMA / maximum: nothing to canonicalise.  A NaN
+                // can only come from a NaN or an infinity in the features, and the staging loop above has flagged that)
+                amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+                amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
                 if (p.out_f16) {
                     const u32x2 pk = {__builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[0], v[1]}, f16x2)),
                                       __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){v[2], v[3]}, f16x2))};
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_in1_kernel(In1ConvParams p) {
             }
         }
     }
-    range_note(p.rg, __builtin_bit_cast(float, amax_u));
+    range_note(p.rg, amax);
 }
 
 size_t conv_in1_lds_bytes(int T, int F, int parts) { return (size_t)parts * 4 * in1_copy_bytes(T, F) + IN1_TAIL; }
@@ -241,11 +249,11 @@ void pack_conv_in1_weights(int Cout, int kh, int mh, const float* w, float scale
                 }
 }
 
-template <int KS>
+template <int KS, int FC>
 static hipError_t launch_in1_ks(const In1ConvParams& p, hipStream_t s) {
     const size_t lds = conv_in1_lds_bytes(p.T, p.F, p.terms >= 3 ? 2 : 1);
-    auto k3 = conv_in1_kernel<KS, IN1_MH3, 3>;
-    auto k1 = conv_in1_kernel<KS, IN1_MH1, 1>;
+    auto k3 = conv_in1_kernel<KS, IN1_MH3, 3, FC>;
+    auto k1 = conv_in1_kernel<KS, IN1_MH1, 1, FC>;
     static DeviceOnce attr_once;   // per instantiation pair: allow > 64 KB of dynamic LDS
     if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -261,10 +269,10 @@ hipError_t launch_conv_in1(const In1ConvParams& p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     if ((p.terms != 3 && p.terms != 1) || p.F % 4 || p.Cp % 16 || p.Cp < p.Cout || p.Hq < 1 || p.Wq < 1) return hipErrorInvalidValue;
     switch ((p.kh + 3) / 4) {
-        case 4: return launch_in1_ks<4>(p, s);
-        case 5: return launch_in1_ks<5>(p, s);
-        case 6: return launch_in1_ks<6>(p, s);
-        case 8: return launch_in1_ks<8>(p, s);
+        case 4: return p.F == 40 ? launch_in1_ks<4, 40>(p, s) : launch_in1_ks<4, 0>(p, s);
+        case 5: return p.F == 40 ? launch_in1_ks<5, 40>(p, s) : launch_in1_ks<5, 0>(p, s);
+        case 6: return p.F == 40 ? launch_in1_ks<6, 40>(p, s) : launch_in1_ks<6, 0>(p, s);
+        case 8: return p.F == 40 ? launch_in1_ks<8, 40>(p, s) : launch_in1_ks<8, 0>(p, s);
     }
     return hipErrorInvalidValue;
 }
