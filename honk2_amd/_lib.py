@@ -22,7 +22,7 @@ DTYPES = {"f32": KWS_DTYPE_F32, "fp32": KWS_DTYPE_F32, "float32": KWS_DTYPE_F32,
 
 # every symbol include/kws.h declares (tests check the library exports exactly these)
 EXPORTS = (
-    "kws_create", "kws_destroy", "kws_load_weights", "kws_workspace_bytes", "kws_set_workspace", "kws_num_frames",
+    "kws_create", "kws_destroy", "kws_load_weights", "kws_workspace_bytes", "kws_chunk_clips", "kws_set_workspace", "kws_num_frames",
     "kws_mfcc", "kws_mfcc_pcm16", "kws_forward", "kws_forward_wav", "kws_forward_pcm16", "kws_workspace_bytes_windows", "kws_mfcc_windows", "kws_forward_windows", "kws_eval_batch", "kws_plan_name", "kws_plan_detail", "kws_profile_enable",
     "kws_profile_read", "kws_last_error", "kws_abi_version",
 )
@@ -79,6 +79,8 @@ def bind(path):
     lib.kws_load_weights.restype = ci
     lib.kws_workspace_bytes.argtypes = [vp, ci, ci]
     lib.kws_workspace_bytes.restype = sz
+    lib.kws_chunk_clips.argtypes = [vp, ci, ci]
+    lib.kws_chunk_clips.restype = ci
     lib.kws_set_workspace.argtypes = [vp, vp, sz]
     lib.kws_set_workspace.restype = ci
     lib.kws_num_frames.argtypes = [vp, ci]
@@ -365,6 +367,10 @@ class Engine:
 
     def plan_detail(self):
         return self.lib.kws_plan_detail(self.handle).decode()
+
+    def chunk_clips(self, batch, frames):
+        """Clips per chunk of a forward call of `batch` clips (kws_chunk_clips): the unit the fp16 range guard recomputes."""
+        return int(self.lib.kws_chunk_clips(self.handle, int(batch), int(frames)))
 
     def profile_enable(self, on=True):
         check(self.lib.kws_profile_enable(self.handle, int(bool(on))), "kws_profile_enable")

@@ -694,11 +694,45 @@ int chunk_clips(size_t per_clip_elems, int B) {
 
 // clips per launch of a cnn-* plan (KWS_CNN_CHUNK: experiments.  r4, cnn-trad-pool2 fp16 at B = 8 192: 512 clips 2.19 ms, 768 1.91, 1 024 1.79, 1 536 1.78 -- fewer, larger launches win
 // over whole rounds of workgroups; f32 likewise)
+// largest per-clip tensor a call really writes: where every MaxPool is reduced in its conv's accumulators (the default kernels, windows of <= 16 members)
+// the un-pooled maps in cnn_max_elems never exist
+size_t cnn_live_elems(const kws_handle* h) {
+    size_t mx = 1;
+    for (size_t i = 0; i < h->cconv.size(); ++i) {
+        const ConvGeom& g = h->cconv[i].g;
+        const int members = h->d.pool_kh[i] * h->d.pool_kw[i];
+        if (!(h->cconv[i].use_x && members <= 16)) return h->cnn_max_elems;
+        mx = std::max(mx, (size_t)((g.Cout + 15) / 16 * 16) * (g.Ho / h->d.pool_kh[i]) * (g.Wo / h->d.pool_kw[i]));
+    }
+    for (const auto& L : h->clin) mx = std::max(mx, (size_t)L.g.Cout * L.g.Ho * L.g.Wo);
+    return std::min(mx, std::max<size_t>(h->cnn_max_elems, 1));
+}
+
+// bytes per clip a chunk keeps alive between its kernels on the channels-last plans (conv_0's cells, conv_1's cells); 0: another plan
+size_t cnn_live_bytes(const kws_handle* h) {
+    if (!(h->cnn_band_R > 0 || h->cnn_cl1) || !h->cnn_in1) return 0;
+    const size_t esz = h->d.dtype == KWS_DTYPE_F16 ? 2 : 4;
+    size_t n = (size_t)h->cnn_cp[0] * h->cnn_shape[1][1] * h->cnn_shape[1][2];
+    if (h->cnn_band_R > 0) n += (size_t)h->cnn_cp[1] * h->cconv[1].g.Ho * h->cconv[1].g.Wo;
+    return n * esz;
+}
+
+// (r5) Clips per chunk of a cnn-* call.  Rounds 3 - 4 found 1 024 best (larger chunks lost the Infinity Cache between the layers, smaller ones paid the
+// launches); with a chunk's small kernels on a second stream and conv_1 persistent the balance moved: the fixed cost of a chunk's ~10 launches no longer
+// hides, and a chunk is as large as keeps its activations inside the 256 MB cache -- 1 024 clips at least, 4 096 at most (B = 12 288, `fp16`, against
+// 1 024-clip chunks: cnn-one-fstride4 2.12 -> 1.23 ms, cnn-tstride8 1.85 -> 0.98, cnn-tstride4 2.05 -> 1.34, cnn-trad-pool2 2.13 -> 2.07; f32: cnn-tstride8
+// 2.26 -> 1.71, cnn-one-fstride4 3.04 -> 2.55, the large two-conv models within 1 %).  Chunks of a call are equal (to 64 clips), so no short chunk trails.
 int cnn_chunk(const kws_handle* h, int B) {
     static const int env = experiment_int("KWS_CNN_CHUNK", 0);
-    const size_t cap = env > 0 ? (size_t)env : 1024;
-    const size_t fit = ((size_t)1 << 28) / std::max<size_t>(h->cnn_max_elems, 1);     // every activation tensor under 1 GiB (chunk_clips)
-    return (int)std::max<size_t>(1, std::min<size_t>(std::min(fit, cap), (size_t)std::max(B, 1)));
+    const size_t live = cnn_live_bytes(h);
+    size_t cap = 1024;
+    if (live) cap = std::min<size_t>(4096, std::max<size_t>(1024, ((size_t)256 << 20) / live));
+    if (env > 0) cap = (size_t)env;
+    const size_t fit = ((size_t)1 << 28) / std::max<size_t>(cnn_live_elems(h), 1);     // every activation tensor under 1 GiB (chunk_clips)
+    const size_t cb = std::max<size_t>(1, std::min(fit, cap)), b = (size_t)std::max(B, 1);
+    if (b <= cb) return (int)b;
+    const size_t n = (b + cb - 1) / cb;
+    return (int)std::min(cb, ((b + n - 1) / n + 63) / 64 * 64);
 }
 
 // Linears (flat Cin == 1 "convs") over a chunk of clips launch only B/256 workgroups; split K so the chip is filled.
@@ -1624,6 +1658,20 @@ int kws_num_frames(const kws_handle* h, int n_samples) {
     return guarded<int>([&]() -> int {
     if (!h || n_samples < 0) return fail(KWS_EINVAL, "bad argument");
     return 1 + n_samples / h->d.hop_length;
+    });
+}
+
+int kws_chunk_clips(const kws_handle* h, int B, int T) {
+    return guarded<int>([&]() -> int {
+    if (!h || B < 1 || T < 1) return 0;
+    if (h->plan == PLAN_CNN) return cnn_chunk(h, B);
+    if (h->plan == PLAN_RESNET) {
+        if (use_fused(h, T)) return B;
+        const ResnetShape s = resnet_shape(h, T);
+        if (resnet_tiled(h, s)) return tiled_chunk(h, s, B);
+        return chunk_clips((size_t)s.C * s.T * s.F, B);
+    }
+    return B;
     });
 }
 

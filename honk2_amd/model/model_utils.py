@@ -161,3 +161,6 @@ class BaseModel(ABC, nn.Module):
 
     def plan_detail(self):
         return self.engine().plan_detail()
+
+    def chunk_clips(self, batch, frames=101):
+        return self.engine().chunk_clips(batch, frames)

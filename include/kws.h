@@ -143,6 +143,11 @@ int kws_load_weights(kws_handle* h, const char* name, const void* host_ptr, size
 size_t kws_workspace_bytes(const kws_handle* h, int B, int T);
 int kws_set_workspace(kws_handle* h, void* d_ptr, size_t bytes);
 
+/* Clips per CHUNK of a kws_forward* call of B clips (T frames) on this handle's plan: the layer-wise plans walk a batch in chunks
+ * (launch group by launch group), and a chunk is the unit the fp16 range guard recomputes; the fused res8 plan has no chunks
+ * (returns B).  Informational (tests, capacity planning); valid once the weights are loaded. */
+int kws_chunk_clips(const kws_handle* h, int B, int T);
+
 /* Number of feature frames for n_samples input samples: 1 + n_samples / hop_length. */
 int kws_num_frames(const kws_handle* h, int n_samples);
 
