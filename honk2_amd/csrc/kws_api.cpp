@@ -665,7 +665,7 @@ size_t resnet_cl_cells(const kws_handle* h, const ResnetShape& s) {
 
 // clips per launch of the tiled plan: tensors under 1 GiB and under 2^24 cells (conv3x3_tile.hip decodes positions with
 // fp32 reciprocals)
-int chunk_clips(size_t per_clip_elems, int B);
+int chunk_clips(size_t per_clip_elems, int B, size_t cap = 1024);
 int tiled_chunk(const kws_handle* h, const ResnetShape& s, int B) {
     const size_t cells = resnet_cl_cells(h, s);
     // (r5) a chunk is sized by its CELLS, not its clips: ~5.5 M cells of the widest layout (1 024 clips of res15's 101 x 40 map, 4 096 of res26's pooled 50 x 20 one), every
@@ -673,7 +673,11 @@ int tiled_chunk(const kws_handle* h, const ResnetShape& s, int B) {
     // res26 clips a span was 62 steps long (stream 6.35 ms against 5.80 for the pair kernels at B = 4 096), at 4 096 it is 250.
     // (Only where streams can run -- the 16-bit dtypes, 41 - 48 channels; every other plan keeps chunks of <= 1 024 clips, the unit the fp16 range guard
     // recomputes.)
-    int cb = chunk_clips(std::max((size_t)s.C * s.T * s.F, cells * pad8(s.C)), B);
+    // (r5) as for the cnn plans: where three fp32 tensors of more than 1 024 clips fit the 256 MB cache (res8-sized pooled maps of the narrow models), a chunk takes
+    // them -- up to 4 096 -- and the ~10 gated launches per chunk weigh less (res8-narrow: 8 of them are a fifth of a 1 024-clip chunk's 0.2 ms)
+    const size_t live3 = 3 * cells * pad8(s.C) * 4;
+    const size_t cap32 = std::min<size_t>(4096, std::max<size_t>(1024, ((size_t)256 << 20) / std::max<size_t>(live3, 1)));
+    int cb = chunk_clips(std::max((size_t)s.C * s.T * s.F, cells * pad8(s.C)), B, cap32);
     if ((h->d.dtype == KWS_DTYPE_BF16 || h->d.dtype == KWS_DTYPE_F16) && h->t3_stream && pad8(s.C) == 48) {
         size_t cbs = std::max<size_t>(1, std::min<size_t>((size_t)1024 * 5376 / cells, 4096));   // (5 376 = res15's cells at dilation 16, padded sub-maps included: its chunks stay 1 024 clips)
         cbs = std::min(cbs, ((size_t)1 << 28) / std::max<size_t>(cells * pad8(s.C), 1));
@@ -686,9 +690,9 @@ int tiled_chunk(const kws_handle* h, const ResnetShape& s, int B) {
 }
 
 // clips per layer-wise launch: keep every activation tensor under 2^28 elements (1 GiB) and 32-bit indexable
-int chunk_clips(size_t per_clip_elems, int B) {
+int chunk_clips(size_t per_clip_elems, int B, size_t cap) {
     size_t cb = ((size_t)1 << 28) / std::max<size_t>(per_clip_elems, 1);
-    cb = std::max<size_t>(1, std::min<size_t>(cb, 1024));
+    cb = std::max<size_t>(1, std::min<size_t>(cb, cap));
     return (int)std::min<size_t>(cb, (size_t)std::max(B, 1));
 }
 
