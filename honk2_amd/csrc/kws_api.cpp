@@ -785,7 +785,7 @@ size_t act_bytes(const kws_handle* h, int B, int T) {
         const int cb = cnn_chunk(h, B);
         // two flip buffers + split-K partials; with the side stream: a second buffer for what the Linears read, the gated pass's own flip pair, two small
         // buffers between Linears
-        const size_t big = align256(h->cnn_max_elems * cb * 4);
+        const size_t big = align256(cnn_live_elems(h) * cb * 4);      // (the tensors a call really writes: run_cnn carves the same)
         return (h->side ? 6 : 2) * big + (h->side ? 2 * align256(cnn_lin_elems(h) * cb * 4) : 0) + cnn_partial_bytes(h, cb) +
                align256((size_t)8 * h->d.time * h->d.freq * 4 + 4096);
     }
@@ -1171,7 +1171,7 @@ int run_cnn(kws_handle* h, const float* feat, int B, int T, float* logits, char*
     const kws_model_desc& d = h->d;
     if (T != d.time) return fail(KWS_EINVAL, "CNN was built for a different number of frames (config[\"time\"])");
     const int cb = cnn_chunk(h, B);
-    const size_t big = align256(h->cnn_max_elems * cb * 4), part_bytes = cnn_partial_bytes(h, cb);
+    const size_t big = align256(cnn_live_elems(h) * cb * 4), part_bytes = cnn_partial_bytes(h, cb);
     char* w = ws;
     auto carve = [&](size_t n) { float* q = (float*)w; w += n; return q; };
     float* P = carve(big);
