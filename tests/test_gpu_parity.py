@@ -1131,6 +1131,25 @@ def test_two_handles_on_two_streams_are_independent(torch_cuda):
     torch.cuda.synchronize()
     for i in range(4):
         assert torch.equal(out8[i], want8) and torch.equal(out15[i], want15), i
+    # two cnn handles of the same model, each with its own side stream, unit counter and flag words, several chunks per call (conv_cols.hip: persistent workgroups of
+    # BOTH launches share the CUs)
+    _, namec, cfgc, sdc, _, _ = load_golden_model("model_cnn__cnn-trad-pool2.npz")
+    ca, cb = _build(torch, namec, dict(cfgc, dtype="fp16"), sdc), _build(torch, namec, dict(cfgc, dtype="fp16"), sdc)
+    fa = torch.from_numpy(weights.make_features(5000, seed=43)).cuda()
+    fb = torch.from_numpy(weights.make_features(4100, seed=44)).cuda()
+    wa, wb = ca(fa).clone(), cb(fb).clone()
+    assert "two streams" in ca.plan_detail() and "conv_cols" in cb.plan_detail()
+    oa = [torch.empty_like(wa) for _ in range(3)]
+    ob = [torch.empty_like(wb) for _ in range(3)]
+    torch.cuda.synchronize()
+    for i in range(3):
+        with torch.cuda.stream(s8):
+            ca(fa, out=oa[i])
+        with torch.cuda.stream(s15):
+            cb(fb, out=ob[i])
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(oa[i], wa) and torch.equal(ob[i], wb), i
 
 
 @pytest.mark.parametrize("fname,dtype", [("model_resnet__res15.npz", "f32"), ("model_resnet__res15.npz", "bf16"), ("model_resnet__res26.npz", "fp16"),
