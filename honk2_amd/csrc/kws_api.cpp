@@ -679,8 +679,9 @@ int tiled_chunk(const kws_handle* h, const ResnetShape& s, int B) {
     const size_t cap32 = std::min<size_t>(4096, std::max<size_t>(1024, ((size_t)256 << 20) / std::max<size_t>(live3, 1)));
     int cb = chunk_clips(std::max((size_t)s.C * s.T * s.F, cells * pad8(s.C)), B, cap32);
     if ((h->d.dtype == KWS_DTYPE_BF16 || h->d.dtype == KWS_DTYPE_F16) && h->t3_stream && pad8(s.C) == 48) {
-        size_t cbs = std::max<size_t>(1, std::min<size_t>((size_t)1024 * 5376 / cells, 4096));   // (5 376 = res15's cells at dilation 16, padded sub-maps included: its chunks stay 1 024 clips)
-        cbs = std::min(cbs, ((size_t)1 << 28) / std::max<size_t>(cells * pad8(s.C), 1));
+        static const int budget_clips = std::max(1, experiment_int("KWS_T3_CHUNK_BUDGET", 2048));
+        size_t cbs = std::max<size_t>(1, std::min<size_t>((size_t)budget_clips * 5376 / cells, 4096));   // (5 376 = res15's cells at dilation 16, padded sub-maps included: 2 048 res15 clips, 4 096 res26 clips)
+        cbs = std::min(cbs, ((size_t)1 << 29) / std::max<size_t>(cells * pad8(s.C), 1));                 // (two-byte elements: 1 GiB per tensor)
         cb = (int)std::max<size_t>(1, std::min<size_t>(cbs, (size_t)std::max(B, 1)));
     }
     size_t cap = (((size_t)1 << 24) - 4096) / cells;

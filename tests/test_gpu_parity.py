@@ -562,9 +562,9 @@ def test_layerwise_fp16_range_guard(torch_cuda, case):
         dtype = "fp16" if case.endswith("fp16") else "f32"
     sd = weights.make_state_dict(name, cfg, seed=5)
     model = _build(torch, name, dict(cfg, dtype=dtype), sd)
-    n = 1100 if name == "ResNet" else 4200          # (cnn chunks hold up to 4 096 clips: kws_chunk_clips)
-    n_clean = model.chunk_clips(n)                  # the first chunk of the call
-    assert n_clean < n and (name != "ResNet" or n_clean == 1024), (n_clean, n)
+    n = model.chunk_clips(100000) + 104             # a little more than the plan's largest chunk (1 024 - 4 096 clips: kws_chunk_clips)
+    n_clean = model.chunk_clips(n)                  # the first chunk of this call
+    assert 512 <= n_clean < n, (n_clean, n)
     n_big = 76
     feats = weights.make_features(n, seed=9)
     feats[n - n_big:] *= 40000.0                    # the last clips' inputs are large: their activations leave fp16's range, their chunk(s) are recomputed
